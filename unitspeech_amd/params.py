@@ -1,0 +1,253 @@
+"""Parameter inventory of the UnitSpeech diffusion decoder and a self-contained synthetic-weight recipe.
+
+The key names / shapes reproduce the ``state_dict`` layout of the reference decoder
+(`unitspeech/unitspeech.py:125-162` for the U-Net, `:221-233` for ``UnitSpeech``; SURVEY.md §8(b)
+"Checkpoint keys": 230 tensors, 119,145,177 parameters at dim=128, dim_mults=[1,2,4,8]).
+
+No pretrained checkpoint exists offline, so tests and benchmarks use weights generated procedurally
+from ``(seed, tensor name)`` with NumPy's Philox generator.  The generator does not depend on torch's
+RNG streams, so the very same arrays can be loaded into the reference model (golden generation), the
+CPU oracle and the HIP decoder.
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+ATTN_HEADS = 4          # unitspeech/unitspeech.py:79 (fixed at every level)
+ATTN_DIM_HEAD = 32      # unitspeech/unitspeech.py:79
+ATTN_HIDDEN = ATTN_HEADS * ATTN_DIM_HEAD
+GN_GROUPS = 8           # unitspeech/unitspeech.py:47,125
+
+
+@dataclass(frozen=True)
+class DecoderConfig:
+    """Constructor arguments of ``UnitSpeech`` (`unitspeech/unitspeech.py:221`, values from
+    `conf/hydra_config.py:122-131`, `:35`)."""
+    n_feats: int = 80
+    dim: int = 128
+    dim_mults: Tuple[int, ...] = (1, 2, 4, 8)
+    beta_min: float = 0.05
+    beta_max: float = 20.0
+    pe_scale: float = 1000.0
+    spk_emb_dim: int = 256
+
+    @property
+    def temb_dim(self) -> int:
+        return self.dim + self.spk_emb_dim
+
+    @property
+    def n_levels(self) -> int:
+        return len(self.dim_mults)
+
+
+@dataclass
+class ResnetSpec:
+    prefix: str
+    dim_in: int
+    dim_out: int
+    level: int
+
+
+@dataclass
+class AttnSpec:
+    prefix: str
+    dim: int
+    level: int
+
+
+@dataclass
+class ResampleSpec:
+    prefix: str
+    dim: int
+    level: int       # level of the INPUT
+
+
+@dataclass
+class UNetTopology:
+    """Execution-ordered description of `GradLogPEstimator2d` (`unitspeech/unitspeech.py:136-162`)."""
+    downs: List[Tuple[ResnetSpec, ResnetSpec, AttnSpec, "ResampleSpec | None"]] = field(default_factory=list)
+    mid: Tuple[ResnetSpec, AttnSpec, ResnetSpec] = None
+    ups: List[Tuple[ResnetSpec, ResnetSpec, AttnSpec, ResampleSpec]] = field(default_factory=list)
+
+    def resnets(self) -> List[ResnetSpec]:
+        out = []
+        for r1, r2, _, _ in self.downs:
+            out += [r1, r2]
+        out += [self.mid[0], self.mid[2]]
+        for r1, r2, _, _ in self.ups:
+            out += [r1, r2]
+        return out
+
+    def attns(self) -> List[AttnSpec]:
+        return [d[2] for d in self.downs] + [self.mid[1]] + [u[2] for u in self.ups]
+
+
+def unet_topology(cfg: DecoderConfig) -> UNetTopology:
+    dims = [2] + [cfg.dim * m for m in cfg.dim_mults]
+    in_out = list(zip(dims[:-1], dims[1:]))
+    topo = UNetTopology()
+    n_res = len(in_out)
+    for ind, (d_in, d_out) in enumerate(in_out):
+        p = f"estimator.downs.{ind}"
+        last = ind >= n_res - 1
+        topo.downs.append((ResnetSpec(f"{p}.0", d_in, d_out, ind),
+                           ResnetSpec(f"{p}.1", d_out, d_out, ind),
+                           AttnSpec(f"{p}.2", d_out, ind),
+                           None if last else ResampleSpec(f"{p}.3", d_out, ind)))
+    mid = dims[-1]
+    lvl = n_res - 1
+    topo.mid = (ResnetSpec("estimator.mid_block1", mid, mid, lvl),
+                AttnSpec("estimator.mid_attn", mid, lvl),
+                ResnetSpec("estimator.mid_block2", mid, mid, lvl))
+    for ind, (d_in, d_out) in enumerate(reversed(in_out[1:])):
+        p = f"estimator.ups.{ind}"
+        level = n_res - 1 - ind
+        topo.ups.append((ResnetSpec(f"{p}.0", d_out * 2, d_in, level),
+                         ResnetSpec(f"{p}.1", d_in, d_in, level),
+                         AttnSpec(f"{p}.2", d_in, level),
+                         ResampleSpec(f"{p}.3", d_in, level)))
+    return topo
+
+
+def param_shapes(cfg: DecoderConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """name -> shape, in the reference's ``state_dict`` order."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    sh["text_uncon"] = (1, cfg.n_feats, 1)
+    sh["spk_uncon"] = (1, 1, cfg.spk_emb_dim)
+    d = cfg.dim
+    sh["estimator.mlp.0.weight"] = (4 * d, d)
+    sh["estimator.mlp.0.bias"] = (4 * d,)
+    sh["estimator.mlp.2.weight"] = (d, 4 * d)
+    sh["estimator.mlp.2.bias"] = (d,)
+
+    def resnet(r: ResnetSpec):
+        sh[f"{r.prefix}.mlp.1.weight"] = (r.dim_out, cfg.temb_dim)
+        sh[f"{r.prefix}.mlp.1.bias"] = (r.dim_out,)
+        for blk, cin in (("block1", r.dim_in), ("block2", r.dim_out)):
+            sh[f"{r.prefix}.{blk}.block.0.weight"] = (r.dim_out, cin, 3, 3)
+            sh[f"{r.prefix}.{blk}.block.0.bias"] = (r.dim_out,)
+            sh[f"{r.prefix}.{blk}.block.1.weight"] = (r.dim_out,)
+            sh[f"{r.prefix}.{blk}.block.1.bias"] = (r.dim_out,)
+        if r.dim_in != r.dim_out:
+            sh[f"{r.prefix}.res_conv.weight"] = (r.dim_out, r.dim_in, 1, 1)
+            sh[f"{r.prefix}.res_conv.bias"] = (r.dim_out,)
+
+    def attn(a: AttnSpec):
+        sh[f"{a.prefix}.fn.g"] = (1,)
+        sh[f"{a.prefix}.fn.fn.to_qkv.weight"] = (3 * ATTN_HIDDEN, a.dim, 1, 1)
+        sh[f"{a.prefix}.fn.fn.to_out.weight"] = (a.dim, ATTN_HIDDEN, 1, 1)
+        sh[f"{a.prefix}.fn.fn.to_out.bias"] = (a.dim,)
+
+    topo = unet_topology(cfg)
+    for r1, r2, a, ds in topo.downs:
+        resnet(r1); resnet(r2); attn(a)
+        if ds is not None:
+            sh[f"{ds.prefix}.conv.weight"] = (ds.dim, ds.dim, 3, 3)
+            sh[f"{ds.prefix}.conv.bias"] = (ds.dim,)
+    # module registration order in the reference: downs, ups, mid_block1, mid_attn, mid_block2? No:
+    # attributes are registered in assignment order (`unitspeech.py:138-162`): downs, ups (empty lists
+    # first), then mid_*, then ups are *filled*; state_dict order follows registration => downs, ups, mid.
+    for r1, r2, a, us in topo.ups:
+        resnet(r1); resnet(r2); attn(a)
+        sh[f"{us.prefix}.conv.weight"] = (us.dim, us.dim, 4, 4)      # ConvTranspose2d: [C_in, C_out, 4, 4]
+        sh[f"{us.prefix}.conv.bias"] = (us.dim,)
+    resnet(topo.mid[0]); attn(topo.mid[1]); resnet(topo.mid[2])
+    sh["estimator.final_block.block.0.weight"] = (d, d, 3, 3)
+    sh["estimator.final_block.block.0.bias"] = (d,)
+    sh["estimator.final_block.block.1.weight"] = (d,)
+    sh["estimator.final_block.block.1.bias"] = (d,)
+    sh["estimator.final_conv.weight"] = (1, d, 1, 1)
+    sh["estimator.final_conv.bias"] = (1,)
+    return sh
+
+
+def n_params(cfg: DecoderConfig) -> int:
+    return int(sum(int(np.prod(s)) for s in param_shapes(cfg).values()))
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic weights
+# ---------------------------------------------------------------------------------------------
+REZERO_G = 0.02   # g=0.02 keeps the untrained 50-step loop finite; 0.1/0.5 overflow
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    key = int.from_bytes(h[:16], "little")
+    return np.random.Generator(np.random.Philox(key=key))
+
+
+def _uniform(seed: int, name: str, shape: Sequence[int], bound: float) -> np.ndarray:
+    u = _rng(seed, name).random(size=tuple(shape), dtype=np.float32)
+    return ((2.0 * u - 1.0) * np.float32(bound)).astype(np.float32)
+
+
+def _normal(seed: int, name: str, shape: Sequence[int], std: float = 1.0) -> np.ndarray:
+    return (_rng(seed, name).standard_normal(size=tuple(shape), dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+
+def synthetic_state_dict(cfg: DecoderConfig, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic fp32 weights keyed by (seed, name).
+
+    Scale follows torch's default conv/linear init (uniform(+-1/sqrt(fan_in)) for weight and bias);
+    GroupNorm affine is perturbed around (1, 0) so the affine path is exercised; every Rezero gain is
+    REZERO_G and the two learned unconditional embeddings are non-zero (a fresh reference module has
+    g = 0 and spk_uncon = 0, which disables attention and makes `spk_uncon / spk_uncon.norm()` NaN,
+    `unitspeech/unitspeech.py:40,231,358`).
+    """
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in param_shapes(cfg).items():
+        if name == "text_uncon":
+            out[name] = _normal(seed, name, shape, 0.5)
+        elif name == "spk_uncon":
+            out[name] = _normal(seed, name, shape, 1.0)
+        elif name.endswith(".fn.g"):
+            out[name] = np.full(shape, REZERO_G, dtype=np.float32)
+        elif ".block.1." in name:                      # GroupNorm affine
+            if name.endswith("weight"):
+                out[name] = (1.0 + _uniform(seed, name, shape, 0.1)).astype(np.float32)
+            else:
+                out[name] = _uniform(seed, name, shape, 0.1)
+        elif name.endswith(".weight"):
+            if name.endswith(".3.conv.weight") and len(shape) == 4 and shape[2] == 4:
+                fan_in = shape[1] * shape[2] * shape[3]   # torch: fan_in of ConvTranspose weight = size(1)*k*k
+            else:
+                fan_in = int(np.prod(shape[1:]))
+            out[name] = _uniform(seed, name, shape, 1.0 / np.sqrt(fan_in))
+        elif name.endswith(".bias"):
+            wshape = param_shapes(cfg)[name[:-4] + "weight"]
+            if name.endswith(".3.conv.bias") and len(wshape) == 4 and wshape[2] == 4:
+                fan_in = wshape[1] * wshape[2] * wshape[3]
+            else:
+                fan_in = int(np.prod(wshape[1:]))
+            out[name] = _uniform(seed, name, shape, 1.0 / np.sqrt(fan_in))
+        else:
+            raise KeyError(name)
+    return out
+
+
+def synthetic_inputs(cfg: DecoderConfig, B: int, T: int, seed: int = 0, n_steps: int = 0,
+                     lengths: "Sequence[int] | None" = None) -> Dict[str, np.ndarray]:
+    """Seeded decoder inputs (SURVEY.md §8(d) "Synthetic inputs"): z~N(0,1), cond~0.5*N(0,1),
+    unit-norm spk_emb, 0/1 mask from ``lengths`` (all ones when None) and, when n_steps>0, the explicit
+    per-step noise tensor ``noise[n_steps, B, n_feats, T]`` that replaces the reference's
+    ``torch.randn`` draws (`unitspeech/unitspeech.py:367`)."""
+    F = cfg.n_feats
+    d: Dict[str, np.ndarray] = {}
+    d["z"] = _normal(seed, f"in.z.{B}.{T}", (B, F, T))
+    d["cond"] = _normal(seed, f"in.cond.{B}.{T}", (B, F, T), 0.5)
+    spk = _normal(seed, f"in.spk.{B}", (B, 1, cfg.spk_emb_dim))
+    d["spk_emb"] = (spk / np.linalg.norm(spk, axis=-1, keepdims=True)).astype(np.float32)
+    mask = np.ones((B, 1, T), dtype=np.float32)
+    if lengths is not None:
+        for b, L in enumerate(lengths):
+            mask[b, 0, int(L):] = 0.0
+    d["mask"] = mask
+    if n_steps > 0:
+        d["noise"] = _normal(seed, f"in.noise.{B}.{T}.{n_steps}", (n_steps, B, F, T))
+    return d
