@@ -1,0 +1,185 @@
+"""GPU parity tests: the HIP decoder (through the C ABI, via the Python mirror) against the CPU oracle and the
+golden vectors captured from the reference.  Tolerances: single estimator evaluation mean-L1 <= 2e-6 (fp32 noise
+floor measured in SURVEY.md §8(c): 2.5e-7); sampler loops mel-L1 <= 1e-3 (north-star tolerance)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_oracle as O
+from unitspeech_amd import DecoderConfig, GradLogPEstimator2d, UnitSpeech, _lib, synthetic_inputs, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+TINY = DecoderConfig(dim=16)
+FULL = DecoderConfig()
+DEV = "cuda:0"
+
+
+def make_model(cfg, seed=0):
+    m = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, seed).items()}, strict=True)
+    return m.to(DEV).eval()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return make_model(TINY), O.to_torch(synthetic_state_dict(TINY, 0))
+
+
+@pytest.fixture(scope="module")
+def full():
+    return make_model(FULL), O.to_torch(synthetic_state_dict(FULL, 0))
+
+
+def G(d):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in d.items()}
+
+
+def l1(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().mean().item()
+
+
+def test_native_library_is_loaded():
+    lib = _lib.load()
+    assert os.path.basename(lib._name) == "libunitspeech_hip.so"
+    assert os.path.dirname(lib._name).endswith("unitspeech_amd")      # in-tree, not site-packages
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_estimator_eval_vs_golden_and_oracle(golden, tag, tiny, full):
+    model, sd = tiny if tag == "tiny" else full
+    g = G(golden(f"estimator_{tag}"))
+    with torch.no_grad():
+        out = model.estimator(g["x"].to(DEV), g["mask"].to(DEV), g["mu"].to(DEV), g["t"].to(DEV), g["spk_emb"].to(DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    e_gold, e_64 = l1(out, g["out"]), l1(out, g["out_fp64"])
+    ref = O.estimator_forward(sd, g["x"], g["mask"], g["mu"], g["t"], g["spk_emb"])
+    e_or = l1(out, ref)
+    print(f"\n[{tag}] estimator L1 vs golden {e_gold:.3e}  vs fp64 {e_64:.3e}  vs oracle {e_or:.3e}  (mean|out| {g['out'].abs().mean():.3f})")
+    assert e_gold <= 2e-6 and e_or <= 2e-6 and e_64 <= 2e-6
+    # masked frames are exactly zero (output * mask, unitspeech.py:201)
+    assert (out.cpu() * (1 - g["mask"])).abs().max().item() == 0.0
+
+
+def test_estimator_standalone_module(golden, tiny):
+    """GradLogPEstimator2d used on its own (no UnitSpeech parent) gives the same result."""
+    g = G(golden("estimator_tiny"))
+    est = GradLogPEstimator2d(TINY.dim, dim_mults=TINY.dim_mults, pe_scale=TINY.pe_scale, spk_emb_dim=TINY.spk_emb_dim)
+    sd = {k[len("estimator."):]: torch.from_numpy(v) for k, v in synthetic_state_dict(TINY, 0).items() if k.startswith("estimator.")}
+    est.load_state_dict(sd, strict=True)
+    est = est.to(DEV).eval()
+    with torch.no_grad():
+        out = est(g["x"].to(DEV), g["mask"].to(DEV), g["mu"].to(DEV), g["t"].to(DEV), g["spk_emb"].to(DEV))
+    assert l1(out, g["out"]) <= 2e-6
+
+
+@pytest.mark.parametrize("T", [8, 24, 136])
+def test_estimator_ragged_lengths_vs_oracle(tiny, T):
+    """T not a multiple of the 128-pixel tile at any level, partially and fully padded items."""
+    model, sd = tiny
+    inp = G(synthetic_inputs(TINY, 3, T, seed=11, lengths=[T, max(T - 7, 1), 0]))
+    t = torch.tensor([0.37, 0.9, 0.05])
+    with torch.no_grad():
+        out = model.estimator(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), t.to(DEV), inp["spk_emb"].to(DEV))
+    ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["cond"], t, inp["spk_emb"])
+    assert l1(out, ref) <= 2e-6
+    assert out[2].abs().max().item() == 0.0            # fully padded item
+
+
+@pytest.mark.parametrize("w", ["11", "10", "01", "00"])
+def test_loop_tiny_cfg_variants(golden, tiny, w):
+    model, _ = tiny
+    g = G(golden(f"loop_tiny_N10_w{w}"))
+    out = model(g["z"].to(DEV), g["mask"].to(DEV), g["cond"].to(DEV), g["spk_emb"].to(DEV), 10,
+                float(g["w_text"]), float(g["w_spk"]), noise=g["noise"].to(DEV))
+    e = l1(out, g["out"])
+    print(f"\nloop tiny w={w}: mel-L1 {e:.3e} (mean|out| {g['out'].abs().mean():.2f})")
+    assert e <= 1e-3
+
+
+def test_loop_tiny_batched_equals_independent_reference_runs(golden, tiny):
+    model, _ = tiny
+    g = G(golden("loop_tiny_N10_B2"))
+    for mb in (1, 2):
+        model.micro_batch = mb
+        out = model(g["z"].to(DEV), g["mask"].to(DEV), g["cond"].to(DEV), g["spk_emb"].to(DEV), 10, 1.0, 1.0,
+                    noise=g["noise"].to(DEV))
+        assert l1(out, g["out"]) <= 1e-3
+    model.micro_batch = 0
+
+
+@pytest.mark.parametrize("n", [10, 50])
+def test_loop_full_vs_reference_golden(golden, full, n):
+    """BASELINE config: full-size decoder, text+spk CFG; T=64 so the reference run that made the golden took seconds."""
+    model, _ = full
+    g = G(golden(f"loop_full_N{n}"))
+    T = g["z"].shape[-1]
+    inp = G(synthetic_inputs(FULL, 1, T, seed=5, n_steps=n, lengths=[T - 4]))
+    assert abs(inp["noise"].double().abs().sum().item() - float(g["noise_abs_sum"])) < 1e-6 * float(g["noise_abs_sum"])
+    out = model(g["z"].to(DEV), g["mask"].to(DEV), g["cond"].to(DEV), g["spk_emb"].to(DEV), n, 1.0, 1.0,
+                noise=inp["noise"].to(DEV))
+    e = l1(out, g["out"])
+    scale = g["out"].abs().mean().item()
+    print(f"\nloop full N={n}: mel-L1 {e:.3e}  relative {e / scale:.3e}  (mean|out| {scale:.1f})")
+    assert torch.isfinite(out).all()
+    assert e <= 1e-3
+
+
+def test_full_size_eval_at_baseline_shape_vs_oracle(full):
+    """One 3-branch evaluation at the BASELINE shape 80x1024 against the CPU oracle (~10 s of CPU)."""
+    model, sd = full
+    T = 1024
+    inp = G(synthetic_inputs(FULL, 1, T, seed=21, lengths=[T - 40]))
+    x3 = inp["z"].repeat(3, 1, 1)
+    mask3 = inp["mask"].repeat(3, 1, 1)
+    mu3 = torch.cat([sd["text_uncon"].repeat(1, 1, T), inp["cond"], inp["cond"]], 0)
+    spk_un = sd["spk_uncon"] / sd["spk_uncon"].norm()
+    spk3 = torch.cat([inp["spk_emb"], spk_un, inp["spk_emb"]], 0)
+    t3 = torch.full((3,), 0.63)
+    with torch.no_grad():
+        out = model.estimator(x3.to(DEV), mask3.to(DEV), mu3.to(DEV), t3.to(DEV), spk3.to(DEV))
+    ref = O.estimator_forward(sd, x3, mask3, mu3, t3, spk3)
+    e = l1(out, ref)
+    print(f"\nfull-size eval T=1024: L1 {e:.3e} (mean|ref| {ref.abs().mean():.3f})")
+    assert e <= 2e-6
+
+
+def test_builtin_generator_statistics_and_shard_independence(tiny):
+    model, _ = tiny
+    lib = _lib.load()
+    n = 1 << 20
+    buf = torch.empty(n, device=DEV)
+    assert lib.us_fill_normal(C.c_void_p(buf.data_ptr()), n, 7, 3, None) == 0
+    torch.cuda.synchronize()
+    assert abs(buf.mean().item()) < 5e-3 and abs(buf.std().item() - 1) < 5e-3
+    assert abs((buf ** 4).mean().item() - 3) < 0.05
+    # same (seed, utterance, step) stream whatever the batch composition: item 1 of a B=2 run == B=1 run at offset 1
+    T = 16
+    inp = G(synthetic_inputs(TINY, 2, T, seed=9))
+    a = model(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), inp["spk_emb"].to(DEV), 4, 1.0, 1.0,
+              rng="philox", seed=5)
+    b = model(inp["z"][1:].to(DEV), inp["mask"][1:].to(DEV), inp["cond"][1:].to(DEV), inp["spk_emb"][1:].to(DEV), 4, 1.0, 1.0,
+              rng="philox", seed=5, utt_offset=1)
+    assert torch.equal(a[1:], b)
+    c = model(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), inp["spk_emb"].to(DEV), 4, 1.0, 1.0,
+              rng="philox", seed=6)
+    assert not torch.equal(a, c)
+
+
+def test_flop_model_matches_survey(full):
+    model, _ = full
+    eng = model._get_engine()
+    for T in (64, 128, 1024):
+        fl = eng.lib.us_estimator_flops(eng.handle, T)
+        assert fl == pytest.approx(649_461_760 * T + 6_160_384, rel=1e-3)
+
+
+def test_errors_are_reported_not_swallowed(tiny):
+    model, _ = tiny
+    z = torch.zeros(1, 80, 12, device=DEV)          # 12 is not a multiple of 8
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        model(z, torch.ones(1, 1, 12, device=DEV), z, torch.zeros(1, 1, 256, device=DEV), 2, 1.0, 1.0, rng="philox")

@@ -1,0 +1,61 @@
+"""Host-side logic of the Python mirror that needs no GPU: state_dict contract, helpers, loud failure on CPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_oracle as O
+from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_state_dict
+from unitspeech_amd.params import param_shapes
+from unitspeech_amd import util
+
+FULL = DecoderConfig()
+
+
+def test_state_dict_keys_and_shapes_match_reference_contract():
+    m = UnitSpeech(80, 32, [1, 2, 4, 8], 0.05, 20.0, 1000, 256)
+    cfg = DecoderConfig(dim=32)
+    want = param_shapes(cfg)
+    got = m.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    for k, v in got.items():
+        assert tuple(v.shape) == tuple(want[k]), k
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, 0).items()}
+    m.load_state_dict(sd, strict=True)
+    assert m.nparams == sum(v.numel() for v in sd.values())
+
+
+def test_full_size_key_count():
+    assert len(param_shapes(FULL)) == 230
+
+
+def test_helpers_match_oracle():
+    lengths = torch.LongTensor([3, 7, 5])
+    assert torch.equal(util.sequence_mask(lengths, 8), O.sequence_mask(lengths, 8))
+    assert torch.equal(util.sequence_mask(lengths), O.sequence_mask(lengths))
+    for n in (1, 8, 9, 171, 172, 176, 1023, 1024):
+        assert util.fix_len_compatibility(n, 3) == O.fix_len_compatibility(n, 3)
+    dur = torch.tensor([[2., 0., 3., 1.], [1., 1., 1., 1.]])
+    mask = torch.ones(2, 4, 7)
+    mask[1, :, 4:] = 0
+    assert torch.equal(util.generate_path(dur, mask), O.generate_path(dur, mask))
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    m = UnitSpeech(80, 16, [1, 2], 0.05, 20.0, 1000, 8)
+    z = torch.zeros(1, 80, 8)
+    with pytest.raises(RuntimeError, match="ROCm device|HIP"):
+        m.forward(z, torch.ones(1, 1, 8), z, torch.zeros(1, 1, 8), 2, 1.0, 1.0, noise=torch.zeros(2, 1, 80, 8))
+
+
+def test_submodules_are_parameter_containers_only():
+    m = UnitSpeech(80, 16, [1, 2], 0.05, 20.0, 1000, 8)
+    with pytest.raises(RuntimeError, match="fused HIP decoder"):
+        m.estimator.final_block(torch.zeros(1, 16, 80, 8), torch.ones(1, 1, 1, 8))
+
+
+@pytest.mark.parametrize("n", [2, 10, 50, 500])
+def test_host_step_coefficients_bit_exact_vs_oracle(n):
+    m = UnitSpeech(80, 16, [1, 2], 0.05, 20.0, 1000, 8)
+    got = m._step_coefficients(n)
+    ref = O.step_coefficients(n, 0.05, 20.0)
+    np.testing.assert_array_equal(got.numpy(), ref.numpy())

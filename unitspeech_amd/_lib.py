@@ -1,0 +1,71 @@
+"""ctypes binding of libunitspeech_hip.so (the C ABI of include/unitspeech_hip.h).
+
+There is deliberately no fallback: if the library is missing it is built with hipcc, and if that fails
+(or a call returns an error code) a RuntimeError is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import _build
+
+US_OK = 0
+ERRORS = {-1: "EINVAL", -2: "ENOKEY", -3: "ESHAPE", -4: "EWEIGHTS", -5: "EWORKSPACE", -6: "EHIP"}
+
+
+class us_config(C.Structure):
+    _fields_ = [("n_feats", C.c_int32), ("dim", C.c_int32), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 6),
+                ("spk_emb_dim", C.c_int32), ("beta_min", C.c_float), ("beta_max", C.c_float), ("pe_scale", C.c_float)]
+
+
+# symbol -> (restype, argtypes); must list every function declared in include/unitspeech_hip.h
+SIGNATURES = {
+    "us_decoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(us_config)]),
+    "us_decoder_destroy": (C.c_int, [C.c_void_p]),
+    "us_decoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    "us_decoder_num_weights": (C.c_int, [C.c_void_p]),
+    "us_decoder_num_loaded": (C.c_int, [C.c_void_p]),
+    "us_decoder_weight_key": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "us_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "us_sampler_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "us_estimator_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "us_reverse_diffusion": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                                                          C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
+                                                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+    "us_step_coefficients": (C.c_int, [C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float)]),
+    "us_fill_normal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "us_estimator_flops": (C.c_double, [C.c_void_p, C.c_int]),
+    "us_last_error": (C.c_char_p, [C.c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """dlopen the in-tree library (building it first when absent or stale)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB
+        if build_if_missing and (not os.path.exists(path) or os.environ.get("UNITSPEECH_AMD_REBUILD") == "1"):
+            path = _build.build_library()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found and could not be built: the HIP decoder has no CPU fallback")
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError here == missing export
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int, handle=None, what: str = "") -> None:
+    if rc == US_OK:
+        return
+    lib = load()
+    msg = lib.us_last_error(handle)
+    raise RuntimeError(f"libunitspeech_hip: {what} failed with {ERRORS.get(rc, rc)}: {msg.decode() if msg else ''}")

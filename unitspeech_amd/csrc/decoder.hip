@@ -1,0 +1,838 @@
+// Host side of libunitspeech_hip.so: weight store, workspace plan, U-Net schedule and the reverse-diffusion loop
+// behind the C ABI of include/unitspeech_hip.h.  Mirrors `GradLogPEstimator2d.forward` (unitspeech/unitspeech.py:164-201)
+// and `UnitSpeech.reverse_diffusion` (:333-374); the arithmetic lives in conv_igemm.hip / ops.hip / attn.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/unitspeech_hip.h"
+#include "kernels.h"
+
+using namespace us;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;
+};
+
+enum class Kind { RAW, CONV_OIHW, CONVT_IOHW };
+
+struct Slot {
+  std::string key;
+  std::vector<int64_t> shape;
+  Kind kind = Kind::RAW;
+  int bk = 0;            // packing chunk for conv kinds
+  DevBuf buf;            // RAW: reference layout; conv kinds: packed layout
+  bool loaded = false;
+};
+
+struct ConvW {
+  Slot* w = nullptr;
+  Slot* b = nullptr;
+  int cin = 0, cout = 0, kh = 1, kw = 1;
+};
+struct ResnetW {
+  int cin, cout, level;
+  bool first = false;      // 2-channel input layer (direct kernel, raw weights)
+  Slot *mlp_w, *mlp_b;
+  ConvW c1, c2, res;
+  Slot *g1, *b1, *g2, *b2;
+  bool has_res = false;
+  int index = 0;           // position in execution order (tproj / stats slots)
+};
+struct AttnW {
+  int dim, level;
+  Slot* g;
+  ConvW qkv;
+  Slot *out_w, *out_b;
+};
+struct ResampleW {
+  ConvW conv;
+  int dim, level;
+};
+
+int pick_bk(int cin) { return (cin % 32 == 0) ? 32 : 16; }
+
+}  // namespace
+
+struct us_decoder {
+  us_config cfg{};
+  int device = 0;
+  std::vector<std::unique_ptr<Slot>> slots;
+  std::map<std::string, Slot*> by_key;
+  std::vector<int> C;   // channels per level
+  // topology
+  struct Down { ResnetW r1, r2; AttnW a; bool has_ds; ResampleW ds; };
+  struct Up { ResnetW r1, r2; AttnW a; ResampleW us; };
+  std::vector<Down> downs;
+  ResnetW mid1, mid2;
+  AttnW mid_attn;
+  std::vector<Up> ups;
+  ConvW final_conv3;
+  Slot *final_g, *final_b, *final_w1, *final_b1;
+  Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
+  int n_resnets = 0;
+  std::string err;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    g_last_error = buf;
+    return code;
+  }
+
+  Slot* add(const std::string& key, std::vector<int64_t> shape, Kind kind = Kind::RAW, int bk = 0) {
+    slots.emplace_back(new Slot());
+    Slot* s = slots.back().get();
+    s->key = key;
+    s->shape = std::move(shape);
+    s->kind = kind;
+    s->bk = bk;
+    by_key[key] = s;
+    return s;
+  }
+
+  ConvW add_conv(const std::string& p, int cout, int cin, int k, bool bias, bool transposed = false) {
+    ConvW c;
+    c.cin = cin; c.cout = cout; c.kh = c.kw = k;
+    if (transposed)
+      c.w = add(p + ".weight", {cin, cout, k, k}, Kind::CONVT_IOHW, pick_bk(cin));
+    else
+      c.w = add(p + ".weight", {cout, cin, k, k}, Kind::CONV_OIHW, pick_bk(cin));
+    c.b = bias ? add(p + ".bias", {cout}) : nullptr;
+    return c;
+  }
+
+  ResnetW add_resnet(const std::string& p, int cin, int cout, int level) {
+    ResnetW r;
+    r.cin = cin; r.cout = cout; r.level = level;
+    r.first = (cin % 16 != 0);
+    const int temb = cfg.dim + cfg.spk_emb_dim;
+    r.mlp_w = add(p + ".mlp.1.weight", {cout, temb});
+    r.mlp_b = add(p + ".mlp.1.bias", {cout});
+    if (r.first) {
+      r.c1.cin = cin; r.c1.cout = cout; r.c1.kh = r.c1.kw = 3;
+      r.c1.w = add(p + ".block1.block.0.weight", {cout, cin, 3, 3});
+      r.c1.b = add(p + ".block1.block.0.bias", {cout});
+    } else {
+      r.c1 = add_conv(p + ".block1.block.0", cout, cin, 3, true);
+    }
+    r.g1 = add(p + ".block1.block.1.weight", {cout});
+    r.b1 = add(p + ".block1.block.1.bias", {cout});
+    r.c2 = add_conv(p + ".block2.block.0", cout, cout, 3, true);
+    r.g2 = add(p + ".block2.block.1.weight", {cout});
+    r.b2 = add(p + ".block2.block.1.bias", {cout});
+    r.has_res = cin != cout;
+    if (r.has_res) {
+      if (r.first) {
+        r.res.cin = cin; r.res.cout = cout;
+        r.res.w = add(p + ".res_conv.weight", {cout, cin, 1, 1});
+        r.res.b = add(p + ".res_conv.bias", {cout});
+      } else {
+        r.res = add_conv(p + ".res_conv", cout, cin, 1, true);
+      }
+    }
+    r.index = n_resnets++;
+    return r;
+  }
+
+  AttnW add_attn(const std::string& p, int dim, int level) {
+    AttnW a;
+    a.dim = dim; a.level = level;
+    a.g = add(p + ".fn.g", {1});
+    a.qkv = add_conv(p + ".fn.fn.to_qkv", 3 * kHidden, dim, 1, false);
+    a.out_w = add(p + ".fn.fn.to_out.weight", {dim, kHidden, 1, 1});
+    a.out_b = add(p + ".fn.fn.to_out.bias", {dim});
+    return a;
+  }
+
+  // key order == reference state_dict order (downs, ups, mid, final; unitspeech/unitspeech.py:136-162)
+  void build() {
+    const int L = cfg.n_mults;
+    C.resize(L);
+    for (int i = 0; i < L; ++i) C[i] = cfg.dim * cfg.dim_mults[i];
+    text_uncon = add("text_uncon", {1, cfg.n_feats, 1});
+    spk_uncon = add("spk_uncon", {1, 1, cfg.spk_emb_dim});
+    mlp0_w = add("estimator.mlp.0.weight", {4 * cfg.dim, cfg.dim});
+    mlp0_b = add("estimator.mlp.0.bias", {4 * cfg.dim});
+    mlp2_w = add("estimator.mlp.2.weight", {cfg.dim, 4 * cfg.dim});
+    mlp2_b = add("estimator.mlp.2.bias", {cfg.dim});
+    downs.resize(L);
+    for (int l = 0; l < L; ++l) {
+      std::string p = "estimator.downs." + std::to_string(l);
+      int cin = l == 0 ? 2 : C[l - 1];
+      downs[l].r1 = add_resnet(p + ".0", cin, C[l], l);
+      downs[l].r2 = add_resnet(p + ".1", C[l], C[l], l);
+      downs[l].a = add_attn(p + ".2", C[l], l);
+      downs[l].has_ds = l < L - 1;
+      if (downs[l].has_ds) {
+        downs[l].ds.conv = add_conv(p + ".3.conv", C[l], C[l], 3, true);
+        downs[l].ds.dim = C[l];
+        downs[l].ds.level = l;
+      }
+    }
+    ups.resize(L - 1);
+    for (int u = 0; u < L - 1; ++u) {
+      std::string p = "estimator.ups." + std::to_string(u);
+      int level = L - 1 - u;
+      int cout = C[level - 1];
+      ups[u].r1 = add_resnet(p + ".0", 2 * C[level], cout, level);
+      ups[u].r2 = add_resnet(p + ".1", cout, cout, level);
+      ups[u].a = add_attn(p + ".2", cout, level);
+      ups[u].us.conv = add_conv(p + ".3.conv", cout, cout, 4, true, true);
+      ups[u].us.dim = cout;
+      ups[u].us.level = level;
+    }
+    mid1 = add_resnet("estimator.mid_block1", C[L - 1], C[L - 1], L - 1);
+    mid_attn = add_attn("estimator.mid_attn", C[L - 1], L - 1);
+    mid2 = add_resnet("estimator.mid_block2", C[L - 1], C[L - 1], L - 1);
+    final_conv3 = add_conv("estimator.final_block.block.0", cfg.dim, cfg.dim, 3, true);
+    final_g = add("estimator.final_block.block.1.weight", {cfg.dim});
+    final_b = add("estimator.final_block.block.1.bias", {cfg.dim});
+    final_w1 = add("estimator.final_conv.weight", {1, cfg.dim, 1, 1});
+    final_b1 = add("estimator.final_conv.bias", {1});
+  }
+};
+
+namespace {
+
+#define US_HIP(h, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess) return (h)->fail(US_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+size_t numel(const std::vector<int64_t>& s) {
+  size_t n = 1;
+  for (auto v : s) n *= (size_t)v;
+  return n;
+}
+
+// ---- workspace arena --------------------------------------------------------------------------------
+struct Arena {
+  char* base;
+  size_t off = 0, cap;
+  explicit Arena(void* b, size_t c) : base(static_cast<char*>(b)), cap(c) {}
+  template <typename T>
+  T* alloc(size_t count) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+struct Buffers {
+  float *in2, *posemb, *mlp_h, *temb, *tproj;
+  std::vector<size_t> tproj_off;   // per resnet, in floats
+  int tproj_ld = 0;
+  double* stats;                   // [n_gn][Bp][8][2]
+  size_t stats_count = 0;
+  std::vector<float*> D, P, Q, S1, S2, QKV, CAT;
+  float* U0;
+  float *part_ctx, *part_m, *part_s, *ctx, *weff;
+};
+
+void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
+  const int L = h->cfg.n_mults, F = h->cfg.n_feats;
+  const size_t B = (size_t)Bp;
+  b.in2 = A.alloc<float>(B * F * T * 2);
+  b.posemb = A.alloc<float>(B * h->cfg.dim);
+  b.mlp_h = A.alloc<float>(B * 4 * h->cfg.dim);
+  b.temb = A.alloc<float>(B * (h->cfg.dim + h->cfg.spk_emb_dim));
+  // per-resnet time projections, one row block per resnet
+  b.tproj_off.assign(h->n_resnets, 0);
+  size_t toff = 0;
+  auto reg = [&](const ResnetW& r) { b.tproj_off[r.index] = toff; toff += B * r.cout; };
+  for (auto& d : h->downs) { reg(d.r1); reg(d.r2); }
+  reg(h->mid1); reg(h->mid2);
+  for (auto& u : h->ups) { reg(u.r1); reg(u.r2); }
+  b.tproj = A.alloc<float>(toff);
+  b.stats_count = (size_t)(2 * h->n_resnets + 1) * B * kGroups * 2;
+  b.stats = A.alloc<double>(b.stats_count);
+  b.D.assign(L, nullptr); b.P.assign(L, nullptr); b.Q.assign(L, nullptr); b.S1.assign(L, nullptr);
+  b.S2.assign(L, nullptr); b.QKV.assign(L, nullptr); b.CAT.assign(L, nullptr);
+  size_t max_n = 0;
+  int max_c = 0;
+  for (int l = 0; l < L; ++l) {
+    size_t n = (size_t)(F >> l) * (T >> l);
+    size_t c = h->C[l];
+    if (n > max_n) max_n = n;
+    if ((int)c > max_c) max_c = (int)c;
+    if (l > 0) b.D[l] = A.alloc<float>(B * n * h->C[l - 1]);
+    b.P[l] = A.alloc<float>(B * n * c);
+    b.Q[l] = A.alloc<float>(B * n * c);
+    b.S1[l] = A.alloc<float>(B * n * c);
+    b.S2[l] = A.alloc<float>(B * n * c);
+    b.QKV[l] = A.alloc<float>(B * n * 3 * kHidden);
+    if (l > 0) b.CAT[l] = A.alloc<float>(B * n * 2 * c);
+  }
+  b.U0 = A.alloc<float>(B * (size_t)F * T * h->C[0]);
+  size_t nch = attn_nchunks((int)max_n);
+  b.part_ctx = A.alloc<float>(B * nch * kHeads * kDimHead * kDimHead);
+  b.part_m = A.alloc<float>(B * nch * kHidden);
+  b.part_s = A.alloc<float>(B * nch * kHidden);
+  b.ctx = A.alloc<float>(B * kHeads * kDimHead * kDimHead);
+  b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
+}
+
+// ---- one estimator evaluation -------------------------------------------------------------------------
+struct EvalCtx {
+  us_decoder* h;
+  hipStream_t s;
+  Buffers* b;
+  int Bp, T;
+  const float* mask;   // [Bm][T]
+  int Bm;
+  int gn_slot = 0;
+};
+
+double* next_stats(EvalCtx& e) {
+  double* p = e.b->stats + (size_t)(e.gn_slot++) * e.Bp * kGroups * 2;
+  return p;
+}
+
+void set_mask(EvalCtx& e, ConvArgs& a, int level_in) {
+  a.mask = e.mask;
+  a.mask_ld = e.T;
+  a.mask_step = 1 << level_in;
+  a.mask_bmod = e.Bm;
+}
+
+ConvArgs base_args(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int Hin, int Win, float* out, int out_ld, int Hout,
+                   int Wout) {
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.in = in; a.in_ld = in_ld;
+  a.wt = w.w->buf.p;
+  a.bias = w.b ? w.b->buf.p : nullptr;
+  a.out = out; a.out_ld = out_ld;
+  a.B = e.Bp; a.Hin = Hin; a.Win = Win; a.Cin = w.cin; a.Hout = Hout; a.Wout = Wout; a.Cout = w.cout;
+  a.Hs = Hout; a.Ws = Wout; a.ostep = 1; a.istride = 1;
+  a.bk = w.w->bk;
+  a.mask_bmod = 1;
+  return a;
+}
+
+hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
+  const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
+  ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
+  a.ntaps = 9;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      a.dy[ky * 3 + kx] = (signed char)(ky - 1);
+      a.dx[ky * 3 + kx] = (signed char)(kx - 1);
+      a.wtap[ky * 3 + kx] = (unsigned char)(ky * 3 + kx);
+    }
+  set_mask(e, a, level);
+  a.stats = stats;
+  return launch_conv_igemm(a, e.s);
+}
+
+hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, bool masked, float* out, int out_ld,
+                   const float* add, int add_ld, const float* alpha, const float* wt_override, long long wt_bstride,
+                   const float* bias_override) {
+  const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
+  ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
+  a.ntaps = 1;
+  if (masked) set_mask(e, a, level);
+  a.add = add; a.add_ld = add_ld; a.alpha = alpha;
+  if (wt_override) { a.wt = wt_override; a.wt_bstride = wt_bstride; a.bias = bias_override; }
+  return launch_conv_igemm(a, e.s);
+}
+
+hipError_t conv_down(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld) {
+  const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
+  ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H / 2, W / 2);
+  a.ntaps = 9;
+  a.istride = 2;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      a.dy[ky * 3 + kx] = (signed char)(ky - 1);
+      a.dx[ky * 3 + kx] = (signed char)(kx - 1);
+      a.wtap[ky * 3 + kx] = (unsigned char)(ky * 3 + kx);
+    }
+  set_mask(e, a, level);
+  return launch_conv_igemm(a, e.s);
+}
+
+// ConvTranspose2d(k=4, s=2, p=1): output row oy = 2*iy - 1 + ky.  Output phase py = oy & 1 receives exactly two
+// kernel rows: py=0 -> (ky=1, iy=m), (ky=3, iy=m-1); py=1 -> (ky=2, iy=m), (ky=0, iy=m+1)   (same along x).
+hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld) {
+  const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
+  static const int KY[2][2] = {{1, 3}, {2, 0}};
+  static const int DY[2][2] = {{0, -1}, {0, 1}};
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, 2 * H, 2 * W);
+      a.Hs = H; a.Ws = W; a.ostep = 2; a.oy0 = py; a.ox0 = px;
+      a.ntaps = 4;
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+          a.dy[i * 2 + j] = (signed char)DY[py][i];
+          a.dx[i * 2 + j] = (signed char)DY[px][j];
+          a.wtap[i * 2 + j] = (unsigned char)(KY[py][i] * 4 + KY[px][j]);
+        }
+      set_mask(e, a, level);
+      hipError_t err = launch_conv_igemm(a, e.s);
+      if (err != hipSuccess) return err;
+    }
+  return hipSuccess;
+}
+
+hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* stats, const Slot* g, const Slot* bta,
+                    const float* temb, const float* res, int res_ld, bool res_masked, float* out, int out_ld) {
+  GnApplyArgs a;
+  memset(&a, 0, sizeof a);
+  a.y = y; a.y_ld = C;
+  a.stats = stats;
+  a.gamma = g->buf.p; a.beta = bta->buf.p;
+  a.mask = e.mask; a.mask_ld = e.T; a.mask_step = 1 << level; a.mask_bmod = e.Bm;
+  a.temb = temb; a.temb_ld = C;
+  a.res = res; a.res_ld = res_ld; a.res_masked = res_masked ? 1 : 0;
+  a.out = out; a.out_ld = out_ld;
+  a.B = e.Bp; a.H = e.h->cfg.n_feats >> level; a.W = e.T >> level; a.C = C;
+  return launch_gn_apply(a, e.s);
+}
+
+#define CK(expr)                          \
+  do {                                    \
+    hipError_t _e = (expr);               \
+    if (_e != hipSuccess) return _e;      \
+  } while (0)
+
+// ResnetBlock (unitspeech/unitspeech.py:58-75)
+hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, float* out, int out_ld) {
+  Buffers& b = *e.b;
+  const int l = r.level;
+  float* S1 = b.S1[l];
+  float* S2 = b.S2[l];
+  const float* tproj = b.tproj + b.tproj_off[r.index];
+  double* st1 = next_stats(e);
+  double* st2 = next_stats(e);
+  CK(conv3x3(e, r.c1, in, in_ld, l, S1, r.cout, st1));
+  CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, S1, r.cout));
+  CK(conv3x3(e, r.c2, S1, r.cout, l, S2, r.cout, st2));
+  if (r.has_res) {
+    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, nullptr, 0, false, out, out_ld));
+    CK(conv1x1(e, r.res, in, in_ld, l, true, out, out_ld, out, out_ld, nullptr, nullptr, 0, nullptr));
+  } else {
+    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, in, in_ld, true, out, out_ld));
+  }
+  return hipSuccess;
+}
+
+// Residual(Rezero(LinearAttention)) (unitspeech/unitspeech.py:78-106)
+hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, float* out, int out_ld) {
+  Buffers& b = *e.b;
+  const int l = at.level;
+  const int n = (e.h->cfg.n_feats >> l) * (e.T >> l);
+  const int nch = attn_nchunks(n);
+  float* qkv = b.QKV[l];
+  CK(conv1x1(e, at.qkv, in, in_ld, l, false, qkv, 3 * kHidden, nullptr, 0, nullptr, nullptr, 0, nullptr));
+  CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
+  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, e.s));
+  const int bk = pick_bk(kHidden);
+  CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s));
+  ConvW eff;
+  eff.cin = kHidden; eff.cout = at.dim;
+  Slot tmp;             // only .bk / .buf are read by base_args
+  tmp.bk = bk; tmp.buf.p = b.weff;
+  eff.w = &tmp; eff.b = nullptr;
+  return conv1x1(e, eff, qkv, 3 * kHidden, l, false, out, out_ld, in, in_ld, at.g->buf.p, b.weff, (long long)at.dim * kHidden,
+                 at.out_b->buf.p);
+}
+
+hipError_t time_embedding(EvalCtx& e, const float* t, const float* spk) {
+  us_decoder* h = e.h;
+  Buffers& b = *e.b;
+  const int dim = h->cfg.dim, S = h->cfg.spk_emb_dim, td = dim + S;
+  CK(launch_pos_emb(t, b.posemb, e.Bp, dim, h->cfg.pe_scale, e.s));
+  CK(launch_linear(b.posemb, dim, h->mlp0_w->buf.p, h->mlp0_b->buf.p, b.mlp_h, 4 * dim, e.Bp, dim, 4 * dim, false, e.s));
+  CK(launch_linear(b.mlp_h, 4 * dim, h->mlp2_w->buf.p, h->mlp2_b->buf.p, b.temb, td, e.Bp, 4 * dim, dim, true, e.s));
+  CK(launch_copy_rows(spk, S, e.Bp, b.temb + dim, td, e.Bp, S, e.s));
+  auto proj = [&](const ResnetW& r) {
+    return launch_linear(b.temb, td, r.mlp_w->buf.p, r.mlp_b->buf.p, b.tproj + b.tproj_off[r.index], r.cout, e.Bp, td, r.cout, true,
+                         e.s);
+  };
+  for (auto& d : h->downs) { CK(proj(d.r1)); CK(proj(d.r2)); }
+  CK(proj(h->mid1)); CK(proj(h->mid2));
+  for (auto& u : h->ups) { CK(proj(u.r1)); CK(proj(u.r2)); }
+  return hipSuccess;
+}
+
+// x: [Bx][F][T]; mu: [Bmu][F][T]; items b' < n_text_uncond use text_uncon instead of mu; spk: [Bp][S]; t: [Bp]
+hipError_t estimator_eval(EvalCtx& e, const float* x, int Bx, const float* mu, int Bmu, int n_text_uncond, const float* t,
+                          const float* spk, float* out) {
+  us_decoder* h = e.h;
+  Buffers& b = *e.b;
+  const int L = h->cfg.n_mults, F = h->cfg.n_feats, T = e.T;
+  e.gn_slot = 0;
+  CK(hipMemsetAsync(b.stats, 0, b.stats_count * sizeof(double), e.s));
+  CK(time_embedding(e, t, spk));
+  CK(launch_stack_inputs(x, Bx, mu, Bmu, n_text_uncond, h->text_uncon->buf.p, e.mask, e.Bm, b.in2, e.Bp, F, T, e.s));
+
+  const float* cur = nullptr;
+  int cur_ld = 0;
+  for (int l = 0; l < L; ++l) {
+    auto& d = h->downs[l];
+    const int c = h->C[l];
+    if (l == 0) {
+      // first ResnetBlock: 2-channel convs on the direct kernel
+      const ResnetW& r = d.r1;
+      double* st1 = next_stats(e);
+      double* st2 = next_stats(e);
+      CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], b.Q[0], e.Bp, F, T, c, e.s));
+      CK(launch_gn_stats(b.S1[0], c, e.Bp, F * T, c, st1, e.s));
+      CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, b.S1[0], c));
+      CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
+      CK(gn_apply(e, b.S2[0], 0, c, st2, r.g2, r.b2, nullptr, b.Q[0], c, false, b.P[0], c));
+    } else {
+      CK(resnet(e, d.r1, cur, cur_ld, b.P[l], c));
+    }
+    CK(resnet(e, d.r2, b.P[l], c, b.Q[l], c));
+    float* hid = l == 0 ? b.P[0] : b.CAT[l] + c;
+    int hid_ld = l == 0 ? c : 2 * c;
+    CK(attention(e, d.a, b.Q[l], c, hid, hid_ld));
+    if (d.has_ds) {
+      CK(conv_down(e, d.ds.conv, hid, hid_ld, l, b.D[l + 1], c));
+      cur = b.D[l + 1];
+      cur_ld = c;
+    } else {
+      cur = hid;
+      cur_ld = hid_ld;
+    }
+  }
+  const int lm = L - 1, cm = h->C[lm];
+  CK(resnet(e, h->mid1, cur, cur_ld, b.P[lm], cm));
+  CK(attention(e, h->mid_attn, b.P[lm], cm, b.Q[lm], cm));
+  float* xcat = L > 1 ? b.CAT[lm] : b.P[lm];
+  CK(resnet(e, h->mid2, b.Q[lm], cm, xcat, L > 1 ? 2 * cm : cm));
+  const float* fin = xcat;
+  int fin_ld = cm;
+  for (int u = 0; u < L - 1; ++u) {
+    auto& up = h->ups[u];
+    const int l = up.r1.level, co = up.r1.cout;
+    CK(resnet(e, up.r1, b.CAT[l], 2 * h->C[l], b.P[l], co));
+    CK(resnet(e, up.r2, b.P[l], co, b.Q[l], co));
+    CK(attention(e, up.a, b.Q[l], co, b.P[l], co));
+    float* dst = (l - 1 >= 1) ? b.CAT[l - 1] : b.U0;
+    int dst_ld = (l - 1 >= 1) ? 2 * h->C[l - 1] : h->C[0];
+    CK(conv_up(e, up.us.conv, b.P[l], co, l, dst, dst_ld));
+    fin = dst;
+    fin_ld = dst_ld;
+  }
+  // final Block + 1x1 projection (unitspeech/unitspeech.py:198-201)
+  double* stf = next_stats(e);
+  const int c0 = h->C[0];
+  CK(conv3x3(e, h->final_conv3, fin, fin_ld, 0, b.S1[0], c0, stf));
+  CK(gn_apply(e, b.S1[0], 0, c0, stf, h->final_g, h->final_b, nullptr, nullptr, 0, false, b.S1[0], c0));
+  CK(launch_final_conv(b.S1[0], c0, h->final_w1->buf.p, h->final_b1->buf.p, e.mask, T, e.Bm, out, e.Bp, F, T, c0, e.s));
+  return hipSuccess;
+}
+
+int check_ready(us_decoder* h) {
+  for (auto& s : h->slots)
+    if (!s->loaded) return h->fail(US_EWEIGHTS, "weight '%s' has not been loaded", s->key.c_str());
+  return US_OK;
+}
+
+int check_shape(us_decoder* h, int Bp, int T) {
+  const int q = 1 << (h->cfg.n_mults - 1);
+  if (Bp <= 0 || T <= 0 || T % q != 0 || T % 4 != 0)
+    return h->fail(US_EINVAL, "unsupported shape Bp=%d T=%d (T must be a positive multiple of %d)", Bp, T, q > 4 ? q : 4);
+  if (h->cfg.n_feats % q != 0) return h->fail(US_EINVAL, "n_feats=%d is not divisible by %d", h->cfg.n_feats, q);
+  return US_OK;
+}
+
+}  // namespace
+
+// =======================================================================================================
+// C ABI
+// =======================================================================================================
+extern "C" {
+
+int us_decoder_create(us_handle* out, const us_config* cfg) {
+  if (!out || !cfg) { g_last_error = "null argument"; return US_EINVAL; }
+  if (cfg->n_mults < 1 || cfg->n_mults > 6 || cfg->dim < 16 || cfg->dim % 16 != 0 || cfg->n_feats <= 0 || cfg->spk_emb_dim <= 0 ||
+      cfg->spk_emb_dim % 4 != 0) {
+    g_last_error = "unsupported configuration (dim must be a multiple of 16, 1 <= n_mults <= 6)";
+    return US_EINVAL;
+  }
+  for (int i = 0; i < cfg->n_mults; ++i) {
+    int c = cfg->dim * cfg->dim_mults[i];
+    int cg = c / kGroups;
+    if (cfg->dim_mults[i] < 1 || c % 16 != 0 || (cg & (cg - 1)) != 0) {
+      g_last_error = "unsupported dim_mults (channels/8 must be a power of two)";
+      return US_EINVAL;
+    }
+  }
+  std::unique_ptr<us_decoder> h(new us_decoder());
+  h->cfg = *cfg;
+  if (hipGetDevice(&h->device) != hipSuccess) { g_last_error = "no HIP device"; return US_EHIP; }
+  hipError_t e = conv_igemm_init();
+  if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
+  h->build();
+  for (auto& s : h->slots) {
+    s->buf.n = numel(s->shape);
+    if (hipMalloc(reinterpret_cast<void**>(&s->buf.p), s->buf.n * sizeof(float)) != hipSuccess) {
+      g_last_error = "hipMalloc failed for weight store";
+      for (auto& t : h->slots) if (t->buf.p) (void)hipFree(t->buf.p);
+      return US_EHIP;
+    }
+  }
+  *out = h.release();
+  return US_OK;
+}
+
+int us_decoder_destroy(us_handle h) {
+  if (!h) return US_OK;
+  for (auto& s : h->slots) if (s->buf.p) (void)hipFree(s->buf.p);
+  delete h;
+  return US_OK;
+}
+
+int us_decoder_num_weights(us_handle h) { return h ? (int)h->slots.size() : 0; }
+int us_decoder_num_loaded(us_handle h) {
+  if (!h) return 0;
+  int n = 0;
+  for (auto& s : h->slots) n += s->loaded ? 1 : 0;
+  return n;
+}
+const char* us_decoder_weight_key(us_handle h, int i) {
+  if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
+  return h->slots[i]->key.c_str();
+}
+
+int us_decoder_load_weight(us_handle h, const char* key, const float* data, const int64_t* shape, int ndim, us_stream stream) {
+  if (!h || !key || !data || !shape) { g_last_error = "null argument"; return US_EINVAL; }
+  auto it = h->by_key.find(key);
+  if (it == h->by_key.end()) return h->fail(US_ENOKEY, "unknown state_dict key '%s'", key);
+  Slot* s = it->second;
+  if (ndim != (int)s->shape.size()) return h->fail(US_ESHAPE, "'%s': expected %d dims, got %d", key, (int)s->shape.size(), ndim);
+  for (int i = 0; i < ndim; ++i)
+    if (shape[i] != s->shape[i]) return h->fail(US_ESHAPE, "'%s': dim %d is %lld, expected %lld", key, i, (long long)shape[i], (long long)s->shape[i]);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (s->kind) {
+    case Kind::RAW:
+      US_HIP(h, hipMemcpyAsync(s->buf.p, data, s->buf.n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      break;
+    case Kind::CONV_OIHW:
+      US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
+      break;
+    case Kind::CONVT_IOHW:
+      US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));
+      break;
+  }
+  s->loaded = true;
+  return US_OK;
+}
+
+size_t us_workspace_bytes(us_handle h, int Bp, int T) {
+  if (!h || Bp <= 0 || T <= 0) return 0;
+  Arena A(nullptr, 0);
+  Buffers b;
+  plan(h, A, Bp, T, b);
+  return A.off + 256;
+}
+
+size_t us_sampler_workspace_bytes(us_handle h, int mb, int T, int n_cfg) {
+  if (!h || mb <= 0 || T <= 0 || n_cfg < 1) return 0;
+  const size_t FT = (size_t)h->cfg.n_feats * T;
+  const size_t Bp = (size_t)mb * n_cfg;
+  // xt, score planes, spk rows, t, normalised spk_uncon (+ alignment slack) + one estimator workspace
+  size_t own = (mb * FT + Bp * FT + Bp * h->cfg.spk_emb_dim + Bp + h->cfg.spk_emb_dim) * sizeof(float) + 8 * 256;
+  return own + us_workspace_bytes(h, (int)Bp, T);
+}
+
+int us_estimator_forward(us_handle h, const float* x, const float* mask, const float* mu, const float* t, const float* spk,
+                         float* out, int Bp, int T, void* workspace, size_t workspace_bytes, us_stream stream) {
+  if (!h || !x || !mask || !mu || !t || !spk || !out || !workspace) { g_last_error = "null argument"; return US_EINVAL; }
+  int rc = check_ready(h);
+  if (rc) return rc;
+  rc = check_shape(h, Bp, T);
+  if (rc) return rc;
+  if (workspace_bytes < us_workspace_bytes(h, Bp, T))
+    return h->fail(US_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, us_workspace_bytes(h, Bp, T));
+  Arena A(workspace, workspace_bytes);
+  Buffers b;
+  plan(h, A, Bp, T, b);
+  EvalCtx e{h, static_cast<hipStream_t>(stream), &b, Bp, T, mask, Bp};
+  US_HIP(h, estimator_eval(e, x, Bp, mu, Bp, 0, t, spk, out));
+  return US_OK;
+}
+
+int us_step_coefficients(int N, float beta_min, float beta_max, float* coef) {
+  if (N < 1 || !coef) { g_last_error = "bad argument"; return US_EINVAL; }
+  // fp32 arithmetic in the reference's order (`reverse_diffusion` :338-347, `register_beta` :235-271), including
+  // the fp64 promotion of alphas_cumprod_prev-derived tables (:238-241) before the final fp32 cast (:271).
+  const double hstep = 1.0 / N;
+  std::vector<float> tt(N), acp_ext(N + 1);
+  for (int i = 0; i < N; ++i) {
+    float t = (float)(1.0 - (i + 0.5) * hstep);
+    tt[i] = t;
+    float cum = beta_min * t + (float)(0.5 * ((double)beta_max - (double)beta_min)) * (t * t);
+    acp_ext[i] = expf(-cum);
+  }
+  acp_ext[N] = 1.f;
+  std::vector<float> betas(N), acp(N);
+  for (int j = 0; j < N; ++j) betas[N - 1 - j] = 1.f - acp_ext[j] / acp_ext[j + 1];
+  float prod = 1.f;
+  for (int j = 0; j < N; ++j) {
+    float alpha = 1.f - betas[j];
+    prod = j == 0 ? alpha : prod * alpha;
+    acp[j] = prod;
+  }
+  for (int i = 0; i < N; ++i) {
+    const int idx = N - 1 - i;
+    const double acp_prev_d = idx == 0 ? 1.0 : (double)acp[idx - 1];
+    const float acp_prev = (float)acp_prev_d;
+    const float pv = (float)((double)betas[idx] * (1.0 - acp_prev_d) / (double)(1.f - acp[idx]));
+    const float s1m = sqrtf(1.f - acp[idx]);
+    const float sigma = sqrtf(pv);
+    float* c = coef + (size_t)i * 8;
+    c[0] = 1.f / sqrtf(acp[idx]);
+    c[1] = sqrtf(1.f / acp[idx] - 1.f) * s1m;
+    c[2] = sqrtf(acp_prev);
+    c[3] = sqrtf(1.f - acp_prev - sigma * sigma);
+    c[4] = s1m;
+    c[5] = idx == 0 ? 0.f : sigma;
+    c[6] = tt[i];
+    c[7] = 0.f;
+  }
+  return US_OK;
+}
+
+int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const float* cond, const float* spk, const float* noise,
+                         uint64_t seed, int64_t utt_offset, int B, int T, int N, float w_text, float w_spk, const float* coef_host,
+                         int micro_batch, float* out, void* workspace, size_t workspace_bytes, us_stream stream) {
+  if (!h || !z || !mask || !cond || !spk || !out || !workspace) { g_last_error = "null argument"; return US_EINVAL; }
+  if (N < 1) return h->fail(US_EINVAL, "n_timesteps must be >= 1");
+  int rc = check_ready(h);
+  if (rc) return rc;
+  const bool use_t = w_text > 0.f, use_s = w_spk > 0.f;
+  const int n_cfg = 1 + (use_t ? 1 : 0) + (use_s ? 1 : 0);
+  const int mode = use_t && use_s ? 3 : use_t ? 2 : use_s ? 1 : 0;
+  int mbs = micro_batch > 0 ? micro_batch : 8;
+  if (mbs > B) mbs = B;
+  rc = check_shape(h, mbs * n_cfg, T);
+  if (rc) return rc;
+  const size_t need = us_sampler_workspace_bytes(h, mbs, T, n_cfg);
+  if (workspace_bytes < need) return h->fail(US_EWORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
+
+  std::vector<float> coef_own;
+  if (!coef_host) {
+    coef_own.resize((size_t)N * 8);
+    us_step_coefficients(N, h->cfg.beta_min, h->cfg.beta_max, coef_own.data());
+    coef_host = coef_own.data();
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int F = h->cfg.n_feats, S = h->cfg.spk_emb_dim;
+  const size_t FT = (size_t)F * T;
+
+  Arena A(workspace, workspace_bytes);
+  float* xt = A.alloc<float>((size_t)mbs * FT);
+  float* score = A.alloc<float>((size_t)mbs * n_cfg * FT);
+  float* spk_cfg = A.alloc<float>((size_t)mbs * n_cfg * S);
+  float* tbuf = A.alloc<float>((size_t)mbs * n_cfg);
+  float* spk_un = A.alloc<float>((size_t)S);
+  Buffers bufs;
+  const size_t est_off = (A.off + 255) & ~size_t(255);
+  if (use_s) US_HIP(h, launch_l2_normalize(h->spk_uncon->buf.p, spk_un, S, s));     // :358
+
+  for (int b0 = 0; b0 < B; b0 += mbs) {
+    const int mb = (B - b0) < mbs ? (B - b0) : mbs;
+    const int Bp = mb * n_cfg;
+    Arena AE(static_cast<char*>(workspace) + est_off, workspace_bytes - est_off);
+    plan(h, AE, Bp, T, bufs);
+    const float* z_b = z + (size_t)b0 * FT;
+    const float* cond_b = cond + (size_t)b0 * FT;
+    const float* mask_b = mask + (size_t)b0 * T;
+    const float* spk_b = spk + (size_t)b0 * S;
+    US_HIP(h, launch_mul_mask(z_b, mask_b, xt, mb, F, T, s));                         // xt = z * mask (:349)
+    // speaker rows per CFG branch (:301-317): mode 3 [spk, uncon, spk], mode 2 [spk, spk], mode 1 [uncon, spk]
+    for (int br = 0; br < n_cfg; ++br) {
+      const bool uncon = (mode == 3 && br == 1) || (mode == 1 && br == 0);
+      US_HIP(h, launch_copy_rows(uncon ? spk_un : spk_b, S, uncon ? 1 : mb, spk_cfg + (size_t)br * mb * S, S, mb, S, s));
+    }
+    const int n_text_uncond = use_t ? mb : 0;
+    EvalCtx e{h, s, &bufs, Bp, T, mask_b, mb};
+    for (int i = 0; i < N; ++i) {
+      const float* c = coef_host + (size_t)i * 8;
+      US_HIP(h, launch_fill(tbuf, c[6], Bp, s));
+      US_HIP(h, estimator_eval(e, xt, mb, cond_b, mb, n_text_uncond, tbuf, spk_cfg, score));
+      SamplerArgs sa;
+      memset(&sa, 0, sizeof sa);
+      sa.xt = xt; sa.score = score; sa.mask = mask_b; sa.out = xt;
+      sa.noise = noise ? noise + ((size_t)i * B + b0) * FT : nullptr;
+      sa.B = mb; sa.F = F; sa.T = T; sa.mode = mode;
+      sa.w_text = w_text; sa.w_spk = w_spk;
+      sa.c0 = c[0]; sa.c1 = c[1]; sa.c2 = c[2]; sa.c3 = c[3]; sa.c4 = c[4]; sa.c5 = c[5];
+      sa.seed = seed; sa.utt0 = utt_offset + b0; sa.step = i;
+      US_HIP(h, launch_sampler_update(sa, s));
+    }
+    US_HIP(h, launch_mul_mask(xt, mask_b, out + (size_t)b0 * FT, mb, F, T, s));       // :373
+  }
+  return US_OK;
+}
+
+int us_fill_normal(float* out, size_t n, uint64_t seed, uint64_t key, us_stream stream) {
+  if (!out && n) { g_last_error = "null argument"; return US_EINVAL; }
+  hipError_t e = launch_fill_normal(out, n, seed, key, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return US_EHIP; }
+  return US_OK;
+}
+
+double us_estimator_flops(us_handle h, int T) {
+  if (!h) return 0.0;
+  const int L = h->cfg.n_mults, F = h->cfg.n_feats;
+  auto npx = [&](int l) { return (double)(F >> l) * (T >> l); };
+  double fl = 0.0;
+  auto conv = [&](double n, int cin, int cout, int taps) { fl += 2.0 * n * cin * cout * taps; };
+  auto res = [&](const ResnetW& r) {
+    double n = npx(r.level);
+    conv(n, r.cin, r.cout, 9);
+    conv(n, r.cout, r.cout, 9);
+    if (r.has_res) conv(n, r.cin, r.cout, 1);
+    fl += 2.0 * (h->cfg.dim + h->cfg.spk_emb_dim) * r.cout;
+  };
+  auto att = [&](const AttnW& a) {
+    double n = npx(a.level);
+    conv(n, a.dim, 3 * kHidden, 1);
+    conv(n, kHidden, a.dim, 1);
+    fl += 2.0 * 2.0 * n * kHeads * kDimHead * kDimHead;   // the two einsums
+  };
+  for (auto& d : h->downs) {
+    res(d.r1); res(d.r2); att(d.a);
+    if (d.has_ds) conv(npx(d.ds.level + 1), d.ds.dim, d.ds.dim, 9);
+  }
+  res(h->mid1); att(h->mid_attn); res(h->mid2);
+  for (auto& u : h->ups) {
+    res(u.r1); res(u.r2); att(u.a);
+    conv(npx(u.us.level), u.us.dim, u.us.dim, 16);      // transposed 4x4: 16 MACs per INPUT pixel per channel pair
+  }
+  conv(npx(0), h->cfg.dim, h->cfg.dim, 9);
+  conv(npx(0), h->cfg.dim, 1, 1);
+  fl += 2.0 * (double)h->cfg.dim * 4 * h->cfg.dim * 2;       // time MLP
+  (void)L;
+  return fl;
+}
+
+const char* us_last_error(us_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+}  // extern "C"

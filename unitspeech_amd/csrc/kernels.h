@@ -1,0 +1,116 @@
+// Internal launcher interface between the decoder host code (decoder.hip) and the gfx950 kernels.
+// Activation layout everywhere inside the library: pixel-major "NHWC" fp32, i.e. [B'][H][W][ld] with the
+// channel index fastest and `ld` (>= C) the pixel stride in floats, so that a producer can write straight
+// into one half of a skip-connection concat buffer (unitspeech/unitspeech.py:192).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace us {
+
+constexpr int kHeads = 4;       // unitspeech/unitspeech.py:79
+constexpr int kDimHead = 32;    // unitspeech/unitspeech.py:79
+constexpr int kHidden = kHeads * kDimHead;
+constexpr int kGroups = 8;      // unitspeech/unitspeech.py:47
+constexpr int kMaxTaps = 16;
+
+// ---- implicit-GEMM convolution on fp32 MFMA -------------------------------------------------------
+struct ConvArgs {
+  const float* in;       // [B][Hin][Win][in_ld], channels [0,Cin)
+  const float* wt;       // packed [tap][Cin/BK][Cout][BK]
+  const float* bias;     // [Cout] or null
+  const float* mask;     // frame mask base [mask_bmod][mask_ld] or null; input column ix reads mask[ix*mask_step]
+  const float* add;      // optional addend, pixel-indexed like out
+  const float* alpha;    // optional device scalar: out = add + alpha*(acc + bias)
+  float* out;            // [B][Hout][Wout][out_ld]
+  double* stats;         // optional GroupNorm partial sums [B][8][2] (sum, sumsq) of the stored values
+  long long wt_bstride;  // per-item weight stride in floats (0 = shared weights)
+  int in_ld, out_ld, add_ld;
+  int B, Hin, Win, Cin, Hout, Wout, Cout;
+  int Hs, Ws;            // output sub-grid handled by this launch
+  int oy0, ox0, ostep;   // output pixel = (oy0 + my*ostep, ox0 + mx*ostep)
+  int istride;           // input pixel  = (my*istride + dy[tap], mx*istride + dx[tap])
+  int ntaps;
+  int mask_ld, mask_step, mask_bmod;
+  int bk;                // 16 or 32: channel chunk the weights were packed for
+  signed char dy[kMaxTaps], dx[kMaxTaps];
+  unsigned char wtap[kMaxTaps];
+};
+hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+hipError_t conv_igemm_init();   // one-time function attributes (dynamic LDS size)
+
+// Repack reference-layout weights into [tap][Cin/bk][Cout][bk].
+//   oihw = true : src is Conv2d  [Cout][Cin][KH][KW]
+//   oihw = false: src is ConvTranspose2d [Cin][Cout][KH][KW]
+hipError_t launch_pack_conv_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk,
+                                   hipStream_t s);
+
+// ---- first layer (2 input channels) ---------------------------------------------------------------
+// in2: [Bp][F][T][2] = (mu, x) already masked; writes conv3x3 (pad 1) -> y[Bp][F*T][C] and the ResnetBlock's
+// 1x1 res_conv -> r[Bp][F*T][C].  w3: reference OIHW [C][2][3][3]; w1: [C][2].
+hipError_t launch_first_conv(const float* in2, const float* w3, const float* b3, const float* w1, const float* b1, float* y,
+                             float* r, int Bp, int F, int T, int C, hipStream_t s);
+// Builds in2 from planar inputs.  x: [Bx][F][T], mu: [Bmu][F][T], mu_feat: [F] (text_uncon, broadcast over T);
+// item b' reads x[b' % Bx], mask[b' % Bm] and mu_feat when b' < n_text_uncond, else mu[b' % Bmu].
+hipError_t launch_stack_inputs(const float* x, int Bx, const float* mu, int Bmu, int n_text_uncond, const float* mu_feat,
+                               const float* mask, int Bm, float* in2, int Bp, int F, int T, hipStream_t s);
+
+// ---- GroupNorm(8) + Mish ----------------------------------------------------------------------------
+// stats[B][8][2] += (sum, sumsq) over [n][C] per item; must be zeroed beforehand.
+hipError_t launch_gn_stats(const float* y, int ld, int B, int n, int C, double* stats, hipStream_t s);
+// out = mish(gn(y)) * mask (+ temb[b][c]) (+ res[p][c] * mask)          (Block :46-55, ResnetBlock :69-75)
+struct GnApplyArgs {
+  const float* y; int y_ld;
+  const double* stats;
+  const float* gamma; const float* beta;
+  const float* mask; int mask_ld, mask_step, mask_bmod;   // frame mask, column w reads mask[w*mask_step]
+  const float* temb; int temb_ld;                          // optional [B][temb_ld] per-channel addend
+  const float* res; int res_ld; int res_masked;            // optional residual (times mask when res_masked)
+  float* out; int out_ld;
+  int B, H, W, C;
+};
+hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
+// final_conv (1x1, C->1) of masked input, times mask: out[b][p] = (b0 + sum_c w[c]*h[p][c]*m)*m        (:199-201)
+hipError_t launch_final_conv(const float* h, int ld, const float* w, const float* b0, const float* mask, int mask_ld,
+                             int mask_bmod, float* out, int B, int H, int W, int C, hipStream_t s);
+
+// ---- linear attention --------------------------------------------------------------------------------
+// qkv: [B][n][384] (q | k | v, each heads*32).  Stage 1: per 128-row chunk, column max / sum-exp of k and the
+// partial context exp(k-m)^T v per head.  Stage 2: combine chunks -> ctx[B][4][32][32] (softmax-normalised).
+// Stage 3: fold ctx into to_out: weff[B] packed [1][128/bk][C][bk], weff[c][h*32+d] = sum_e Wout[c][h*32+e]*ctx[h][d][e].
+hipError_t launch_attn_ctx_partial(const float* qkv, int B, int n, float* part_ctx, float* part_m, float* part_s, int nchunks,
+                                   hipStream_t s);
+hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
+                                    float* ctx, hipStream_t s);
+hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s);
+inline int attn_nchunks(int n) { return (n + 127) / 128; }
+
+// ---- small dense layers ----------------------------------------------------------------------------
+// out[r][o] = bias[o] + sum_i W[o][i] * f(in[r][i]),  f = mish when mish_in
+hipError_t launch_linear(const float* in, int in_ld, const float* W, const float* bias, float* out, int out_ld, int rows,
+                         int in_dim, int out_dim, bool mish_in, hipStream_t s);
+// SinusoidalPosEmb (:109-121): emb[r][0:half]=sin, [half:dim]=cos of scale*t[r]*exp(-k*ln(1e4)/(half-1))
+hipError_t launch_pos_emb(const float* t, float* emb, int rows, int dim, float scale, hipStream_t s);
+// dst[r][0:n] = src[src_index ? src_index[r] : r % src_rows][0:n]   (row gather/copy into a strided destination)
+hipError_t launch_copy_rows(const float* src, int src_ld, int src_rows, float* dst, int dst_ld, int rows, int n, hipStream_t s);
+hipError_t launch_fill(float* dst, float value, int n, hipStream_t s);
+// dst = src / ||src||_2 over n elements (spk_uncon normalisation, :358)
+hipError_t launch_l2_normalize(const float* src, float* dst, int n, hipStream_t s);
+
+// ---- sampler ---------------------------------------------------------------------------------------
+// CFG combine (:320-330) + ancestral update (:273-296, :366-370) on [B][F*T] planes.
+// score: [n_cfg*B][F*T] in branch-major order.  mode: 3 = text+spk, 2 = text only, 1 = spk only, 0 = none.
+struct SamplerArgs {
+  const float* xt; const float* score; const float* noise; const float* mask;   // mask [B][T]
+  float* out;
+  int B, F, T, mode;
+  float w_text, w_spk;
+  float c0, c1, c2, c3, c4, c5;
+  // built-in generator (used when noise == null and c5 != 0)
+  unsigned long long seed; long long utt0; int step;
+};
+hipError_t launch_sampler_update(const SamplerArgs& a, hipStream_t s);
+hipError_t launch_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, hipStream_t s);
+hipError_t launch_fill_normal(float* out, size_t n, unsigned long long seed, unsigned long long key, hipStream_t s);
+
+}  // namespace us

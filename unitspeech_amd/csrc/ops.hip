@@ -1,0 +1,482 @@
+// HBM-bound kernels of the decoder: GroupNorm(8)+Mish, the 2-channel first layer, final 1x1 projection,
+// time/speaker embedding MLPs, CFG combine + ancestral sampler update and the counter-based gaussian source.
+// All of them are streaming passes with 16-byte coalesced accesses along the channel (pixel-major layout) or
+// the time axis (planar [B][F][T] boundary tensors); reductions use wave64 shuffles.
+#include "kernels.h"
+
+namespace us {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// Mish (unitspeech/unitspeech.py:13-15): x*tanh(softplus(x)), softplus threshold 20.
+// tanh(log(1+w)) = ((1+w)^2-1)/((1+w)^2+1) = w(w+2)/(w(w+2)+2) with w = e^x: one exp, one divide, no cancellation.
+__device__ __forceinline__ float mish_f(float x) {
+  if (x > 20.f) return x * tanhf(x);   // softplus(x) = x beyond the threshold; tanh(x>20) == 1 in fp32
+  float w = expf(x);
+  float u = w * (w + 2.f);
+  return x * (u / (u + 2.f));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// input stacking: in2[b'][f][t][0:2] = (mu, x) * mask        (unitspeech/unitspeech.py:170 + Block's x*mask :54)
+// ---------------------------------------------------------------------------------------------------
+__global__ void stack_inputs_kernel(const float* __restrict__ x, int Bx, const float* __restrict__ mu, int Bmu, int n_text_uncond,
+                                    const float* __restrict__ mu_feat, const float* __restrict__ mask, int Bm, float* __restrict__ in2,
+                                    int Bp, int F, int T) {
+  const long long total = (long long)Bp * F * T;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int t = (int)(i % T);
+    long long r = i / T;
+    int f = (int)(r % F);
+    int b = (int)(r / F);
+    float m = mask[(long long)(b % Bm) * T + t];
+    float xv = x[((long long)(b % Bx) * F + f) * T + t];
+    float mv = b < n_text_uncond ? mu_feat[f] : mu[((long long)(b % Bmu) * F + f) * T + t];
+    float2 o;
+    o.x = mv * m;
+    o.y = xv * m;
+    reinterpret_cast<float2*>(in2)[i] = o;
+  }
+}
+
+hipError_t launch_stack_inputs(const float* x, int Bx, const float* mu, int Bmu, int n_text_uncond, const float* mu_feat,
+                               const float* mask, int Bm, float* in2, int Bp, int F, int T, hipStream_t s) {
+  long long total = (long long)Bp * F * T;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(stack_inputs_kernel, dim3(blocks), dim3(256), 0, s, x, Bx, mu, Bmu, n_text_uncond, mu_feat, mask, Bm, in2, Bp, F, T);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// first layer: Conv2d(2, C, 3, pad 1) and res_conv Conv2d(2, C, 1) of downs.0.0 (unitspeech.py:48,66)
+// One workgroup = 32 consecutive frames of one mel row; the (3 x 34 x 2) masked input patch sits in LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr int FC_TW = 32;
+__global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict__ in2, const float* __restrict__ w3,
+                                                         const float* __restrict__ b3, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1, float* __restrict__ y, float* __restrict__ r,
+                                                         int F, int T, int C) {
+  __shared__ float patch[3][FC_TW + 2][2];
+  const int b = blockIdx.z, f = blockIdx.y, t0 = blockIdx.x * FC_TW;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * (FC_TW + 2) * 2; i += 256) {
+    int c = i & 1, xx = (i >> 1) % (FC_TW + 2), yy = (i >> 1) / (FC_TW + 2);
+    int ff = f + yy - 1, tt = t0 + xx - 1;
+    float v = 0.f;
+    if (ff >= 0 && ff < F && tt >= 0 && tt < T) v = in2[(((long long)b * F + ff) * T + tt) * 2 + c];
+    patch[yy][xx][c] = v;
+  }
+  __syncthreads();
+  for (int co = tid; co < C; co += 256) {   // (all 256 threads active when C >= 256; C=128 uses half)
+    float w[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) w[i] = w3[co * 18 + i];   // OIHW: [co][ci][ky][kx]
+    const float bb = b3[co], r0 = w1[co * 2], r1 = w1[co * 2 + 1], rb = b1[co];
+    for (int xx = 0; xx < FC_TW; ++xx) {
+      if (t0 + xx >= T) break;
+      float acc = bb;
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[ci * 9 + ky * 3 + kx], patch[ky][xx + kx][ci], acc);
+      long long p = ((long long)b * F + f) * T + t0 + xx;
+      y[p * C + co] = acc;
+      r[p * C + co] = fmaf(r1, patch[1][xx + 1][1], fmaf(r0, patch[1][xx + 1][0], rb));
+    }
+  }
+}
+
+hipError_t launch_first_conv(const float* in2, const float* w3, const float* b3, const float* w1, const float* b1, float* y,
+                             float* r, int Bp, int F, int T, int C, hipStream_t s) {
+  dim3 grid((T + FC_TW - 1) / FC_TW, F, Bp);
+  hipLaunchKernelGGL(first_conv_kernel, grid, dim3(256), 0, s, in2, w3, b3, w1, b1, y, r, F, T, C);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm statistics (standalone; the conv epilogue normally produces them)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ y, int ld, int n, int C, double* __restrict__ stats) {
+  __shared__ double red[kGroups][2];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < kGroups * 2) red[tid >> 1][tid & 1] = 0.0;
+  __syncthreads();
+  const int cg = C / kGroups;
+  const long long total = (long long)n * C;
+  const float* yb = y + (long long)b * n * ld;
+  // thread walks elements i = chunk*256+tid (channel-fastest => coalesced); group changes per element
+  double s1[kGroups], s2[kGroups];
+#pragma unroll
+  for (int g = 0; g < kGroups; ++g) s1[g] = s2[g] = 0.0;
+  for (long long i = blockIdx.x * 256LL + tid; i < total; i += (long long)gridDim.x * 256) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    float v = yb[p * ld + c];
+    int g = c / cg;
+#pragma unroll
+    for (int k = 0; k < kGroups; ++k)
+      if (k == g) { s1[k] += v; s2[k] += (double)v * v; }
+  }
+#pragma unroll
+  for (int g = 0; g < kGroups; ++g) {
+    double a = wave_sum_d(s1[g]), q = wave_sum_d(s2[g]);
+    if ((tid & 63) == 0) { atomicAdd(&red[g][0], a); atomicAdd(&red[g][1], q); }
+  }
+  __syncthreads();
+  if (tid < kGroups * 2) atomicAdd(&stats[((long long)b * kGroups + (tid >> 1)) * 2 + (tid & 1)], red[tid >> 1][tid & 1]);
+}
+
+hipError_t launch_gn_stats(const float* y, int ld, int B, int n, int C, double* stats, hipStream_t s) {
+  long long total = (long long)n * C;
+  int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(blocks, B), dim3(256), 0, s, y, ld, n, C, stats);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm apply + Mish + mask (+ time-embedding addend) (+ masked residual)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
+  const int b = blockIdx.y;
+  const int C4 = a.C >> 2;
+  const int cg = a.C / kGroups;
+  const long long n = (long long)a.H * a.W;
+  const double cnt = (double)n * cg;
+  __shared__ float s_mean[kGroups], s_rstd[kGroups];
+  if (threadIdx.x < kGroups) {
+    const double* st = a.stats + ((long long)b * kGroups + threadIdx.x) * 2;
+    double mean = st[0] / cnt;
+    double var = st[1] / cnt - mean * mean;
+    if (var < 0) var = 0;
+    s_mean[threadIdx.x] = (float)mean;
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  const float* yb = a.y + (long long)b * n * a.y_ld;
+  float* ob = a.out + (long long)b * n * a.out_ld;
+  const float* rb = a.res ? a.res + (long long)b * n * a.res_ld : nullptr;
+  const float* mb = a.mask + (long long)(b % a.mask_bmod) * a.mask_ld;
+  const float* tb = a.temb ? a.temb + (long long)b * a.temb_ld : nullptr;
+  const long long total = n * C4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const long long p = i / C4;
+    const int w = (int)(p % a.W);
+    const float m = mb[w * a.mask_step];
+    const int g = c / cg;           // cg >= 4 is host-checked so a float4 never straddles groups... (cg>=2: per-lane below)
+    f32x4 v = *reinterpret_cast<const f32x4*>(yb + p * a.y_ld + c);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c);
+    f32x4 be = *reinterpret_cast<const f32x4*>(a.beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int gk = (cg >= 4) ? g : (c + k) / cg;
+      float xn = (v[k] - s_mean[gk]) * s_rstd[gk];
+      float z = xn * ga[k] + be[k];
+      o[k] = mish_f(z) * m;
+    }
+    if (tb) {
+      f32x4 te = *reinterpret_cast<const f32x4*>(tb + c);
+      o += te;
+    }
+    if (rb) {
+      f32x4 rr = *reinterpret_cast<const f32x4*>(rb + p * a.res_ld + c);
+      o += a.res_masked ? rr * m : rr;
+    }
+    *reinterpret_cast<f32x4*>(ob + p * a.out_ld + c) = o;
+  }
+}
+
+hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
+  if (a.C % 4 != 0 || a.C % kGroups != 0 || a.y_ld % 4 != 0 || a.out_ld % 4 != 0 || (a.res && a.res_ld % 4 != 0))
+    return hipErrorInvalidValue;
+  long long total = (long long)a.H * a.W * (a.C / 4);
+  int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// final_conv: 1x1, C -> 1 on the masked block output, times mask            (unitspeech.py:199-201)
+// half a wave (32 lanes x float4 = 128 channels per pass) per pixel
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict__ h, int ld, const float* __restrict__ w,
+                                                         const float* __restrict__ b0, const float* __restrict__ mask, int mask_ld,
+                                                         int mask_bmod, float* __restrict__ out, int W, long long n, int C) {
+  const int b = blockIdx.y;
+  const int l32 = threadIdx.x & 31;
+  const long long half0 = (blockIdx.x * 256LL + threadIdx.x) >> 5;
+  const long long nhalf = ((long long)gridDim.x * 256) >> 5;
+  const float* hb = h + (long long)b * n * ld;
+  const float* mb = mask + (long long)(b % mask_bmod) * mask_ld;
+  const float bias = b0[0];
+  for (long long p = half0; p < n; p += nhalf) {
+    float acc = 0.f;
+    for (int c = l32 * 4; c < C; c += 128) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(hb + p * ld + c);
+      f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+      acc += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3];
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (l32 == 0) {
+      float m = mb[(int)(p % W)];
+      out[(long long)b * n + p] = (acc * m + bias) * m;
+    }
+  }
+}
+
+hipError_t launch_final_conv(const float* h, int ld, const float* w, const float* b0, const float* mask, int mask_ld,
+                             int mask_bmod, float* out, int B, int H, int W, int C, hipStream_t s) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
+  long long n = (long long)H * W;
+  int blocks = (int)((n + 7) / 8);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(final_conv_kernel, dim3(blocks, B), dim3(256), 0, s, h, ld, w, b0, mask, mask_ld, mask_bmod, out, W, n, C);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small dense layers: one wave per output element
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int out_ld, int in_dim,
+                                                     int out_dim, int mish_in) {
+  const int r = blockIdx.y;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= out_dim) return;
+  const float* x = in + (long long)r * in_ld;
+  const float* w = W + (long long)o * in_dim;
+  float acc = 0.f;
+  for (int i = lane; i < in_dim; i += 64) {
+    float v = x[i];
+    if (mish_in) v = mish_f(v);
+    acc = fmaf(w[i], v, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[(long long)r * out_ld + o] = acc + (bias ? bias[o] : 0.f);
+}
+
+hipError_t launch_linear(const float* in, int in_ld, const float* W, const float* bias, float* out, int out_ld, int rows,
+                         int in_dim, int out_dim, bool mish_in, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(linear_kernel, dim3((out_dim + 3) / 4, rows), dim3(256), 0, s, in, in_ld, W, bias, out, out_ld, in_dim, out_dim,
+                     mish_in ? 1 : 0);
+  return hipGetLastError();
+}
+
+__global__ void pos_emb_kernel(const float* __restrict__ t, float* __restrict__ emb, int rows, int dim, float scale) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * half) return;
+  const int r = i / half, k = i % half;
+  // emb = exp(arange(half) * -(log(10000)/(half-1))); arg = scale * t * emb      (unitspeech.py:116-119)
+  const float e = (float)(9.210340371976184 / (double)(half - 1));   // math.log(10000)/(half-1) rounded to fp32
+  const float freq = expf((float)k * -e);
+  const float arg = scale * t[r] * freq;
+  emb[(long long)r * dim + k] = sinf(arg);
+  emb[(long long)r * dim + half + k] = cosf(arg);
+}
+
+hipError_t launch_pos_emb(const float* t, float* emb, int rows, int dim, float scale, hipStream_t s) {
+  int total = rows * (dim / 2);
+  hipLaunchKernelGGL(pos_emb_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, emb, rows, dim, scale);
+  return hipGetLastError();
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, int src_ld, int src_rows, float* __restrict__ dst, int dst_ld, int rows,
+                                 int n) {
+  const long long total = (long long)rows * n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int r = (int)(i / n), c = (int)(i % n);
+    dst[(long long)r * dst_ld + c] = src[(long long)(r % src_rows) * src_ld + c];
+  }
+}
+
+hipError_t launch_copy_rows(const float* src, int src_ld, int src_rows, float* dst, int dst_ld, int rows, int n, hipStream_t s) {
+  long long total = (long long)rows * n;
+  if (total <= 0) return hipSuccess;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, s, src, src_ld, src_rows, dst, dst_ld, rows, n);
+  return hipGetLastError();
+}
+
+__global__ void fill_kernel(float* __restrict__ dst, float value, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = value;
+}
+
+hipError_t launch_fill(float* dst, float value, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, value, n);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void l2_normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) acc += src[i] * src[i];
+  acc = wave_sum(acc);
+  const float nrm = sqrtf(acc);
+  for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i] / nrm;
+}
+
+hipError_t launch_l2_normalize(const float* src, float* dst, int n, hipStream_t s) {
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(64), 0, s, src, dst, n);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// counter-based gaussian source: Philox4x32-10 -> 4 uniforms -> 2 Box-Muller pairs
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// normals for the 4 consecutive elements [4*q, 4*q+4) of stream (seed, key)
+__device__ __forceinline__ f32x4 normal4(unsigned long long seed, unsigned long long key, unsigned long long q) {
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)key, (uint32_t)(key >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float k = 2.3283064365386963e-10f;   // 2^-32
+  float u0 = ((float)c[0] + 0.5f) * k, u1 = ((float)c[1] + 0.5f) * k;
+  float u2 = ((float)c[2] + 0.5f) * k, u3 = ((float)c[3] + 0.5f) * k;
+  u0 = fminf(fmaxf(u0, 1e-12f), 1.f);
+  u2 = fminf(fmaxf(u2, 1e-12f), 1.f);
+  float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  return f32x4{r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+}
+
+__global__ void fill_normal_kernel(float* __restrict__ out, size_t n, unsigned long long seed, unsigned long long key) {
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v = normal4(seed, key, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < n) out[q * 4 + k] = v[k];
+  }
+}
+
+hipError_t launch_fill_normal(float* out, size_t n, unsigned long long seed, unsigned long long key, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  size_t nq = (n + 3) / 4;
+  int blocks = (int)((nq + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(blocks), dim3(256), 0, s, out, n, seed, key);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CFG combine + ancestral update.  Operation order follows the reference's tensor expressions so that an
+// identical score gives a bit-identical update (no FMA contraction: explicit __fmul_rn/__fadd_rn).
+//   score = s + w_t*(s - s_tu) + w_s*(s - s_su)                                   (unitspeech.py:322-324)
+//   x0    = c0*xt + c1*score                                                      (:273-278)
+//   mean  = c2*x0 - (c3*score)*c4                                                 (:283-287)
+//   xt'   = (mean + c5*noise) * mask                                              (:370)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sampler_update_kernel(SamplerArgs a) {
+  const long long FT = (long long)a.F * a.T;
+  const long long total = (long long)a.B * FT;
+  const long long BFT = total;
+  for (long long q = blockIdx.x * 256LL + threadIdx.x; q * 4 < total; q += (long long)gridDim.x * 256) {
+    const long long i0 = q * 4;
+    const int b = (int)(i0 / FT);
+    const long long rem = i0 - (long long)b * FT;
+    const int t = (int)(rem % a.T);       // T % 4 == 0 (T is a multiple of 8): the 4 elements share item and row
+    f32x4 x = *reinterpret_cast<const f32x4*>(a.xt + i0);
+    f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + (long long)b * a.T + t);
+    f32x4 sc;
+    if (a.mode == 3) {
+      f32x4 s_tu = *reinterpret_cast<const f32x4*>(a.score + i0);
+      f32x4 s_su = *reinterpret_cast<const f32x4*>(a.score + BFT + i0);
+      f32x4 s = *reinterpret_cast<const f32x4*>(a.score + 2 * BFT + i0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        sc[k] = __fadd_rn(__fadd_rn(s[k], __fmul_rn(a.w_text, __fsub_rn(s[k], s_tu[k]))),
+                          __fmul_rn(a.w_spk, __fsub_rn(s[k], s_su[k])));
+    } else if (a.mode == 2 || a.mode == 1) {
+      f32x4 s_u = *reinterpret_cast<const f32x4*>(a.score + i0);
+      f32x4 s = *reinterpret_cast<const f32x4*>(a.score + BFT + i0);
+      const float w = a.mode == 2 ? a.w_text : a.w_spk;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[k] = __fadd_rn(s[k], __fmul_rn(w, __fsub_rn(s[k], s_u[k])));
+    } else {
+      sc = *reinterpret_cast<const f32x4*>(a.score + i0);
+    }
+    f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.c5 != 0.f) {
+      if (a.noise) {
+        nz = *reinterpret_cast<const f32x4*>(a.noise + i0);
+      } else {
+        // stream key = (utterance, step); counter = element quad inside the utterance => independent of sharding
+        unsigned long long key = ((unsigned long long)(a.utt0 + b) << 20) ^ (unsigned long long)(unsigned)a.step;
+        nz = normal4(a.seed, key, (unsigned long long)(rem >> 2));
+      }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x0 = __fadd_rn(__fmul_rn(a.c0, x[k]), __fmul_rn(a.c1, sc[k]));
+      float mean = __fsub_rn(__fmul_rn(a.c2, x0), __fmul_rn(__fmul_rn(a.c3, sc[k]), a.c4));
+      o[k] = __fmul_rn(__fadd_rn(mean, __fmul_rn(a.c5, nz[k])), m[k]);
+    }
+    *reinterpret_cast<f32x4*>(a.out + i0) = o;
+  }
+}
+
+hipError_t launch_sampler_update(const SamplerArgs& a, hipStream_t s) {
+  if (a.T % 4 != 0) return hipErrorInvalidValue;
+  long long total = (long long)a.B * a.F * a.T;
+  int blocks = (int)((total / 4 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sampler_update_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+__global__ void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out, int B, int F, int T) {
+  const long long total = (long long)B * F * T;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int t = (int)(i % T);
+    int b = (int)(i / ((long long)F * T));
+    out[i] = x[i] * mask[(long long)b * T + t];
+  }
+}
+
+hipError_t launch_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, hipStream_t s) {
+  long long total = (long long)B * F * T;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mul_mask_kernel, dim3(blocks), dim3(256), 0, s, x, mask, out, B, F, T);
+  return hipGetLastError();
+}
+
+}  // namespace us
