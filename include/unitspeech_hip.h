@@ -97,6 +97,15 @@ int us_fill_normal(float* out, size_t n, uint64_t seed, uint64_t key, us_stream 
 /* FLOPs (2*MAC of conv + attention einsums + MLPs) of one estimator evaluation per item. */
 double us_estimator_flops(us_handle h, int T);
 
+/* Sampled kernel timing for the roofline report.  When enabled, the middle evaluation of every
+ * us_reverse_diffusion micro-batch (and every us_estimator_forward) brackets each implicit-GEMM convolution launch,
+ * and the evaluation as a whole, with HIP events on the caller's stream.  us_profile_read waits for the recorded
+ * events and returns the accumulated totals: time and algorithmic FLOPs (2*MAC) of the conv launches, their
+ * count, and the time / count of the sampled evaluations. */
+int us_profile_enable(us_handle h, int enable);
+int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* conv_launches, double* eval_ms,
+                    int64_t* evals, int reset);
+
 /* Last error message of this handle (or of the library when h == NULL). */
 const char* us_last_error(us_handle h);
 

@@ -189,13 +189,16 @@ def main():
     save("loop_tiny_N10_B2", **inp, out=torch.cat(outs, 0), w_text=1.0, w_spk=1.0)
 
     T = 64
+    full64 = build(U, FULL, 0, torch.float64)
     for n in (10, 50):
         inp = tt(synthetic_inputs(FULL, 1, T, seed=5, n_steps=n, lengths=[T - 4]))
         out = run_loop(full_model, inp, n, 1.0, 1.0)
-        print(f"   full N={n}: mean|out|={out.abs().mean():.3f} max={out.abs().max():.1f} finite={bool(torch.isfinite(out).all())}")
+        out64 = run_loop(full64, {k: v.double() for k, v in inp.items()}, n, 1.0, 1.0)
+        print(f"   full N={n}: mean|out|={out.abs().mean():.3f} max={out.abs().max():.1f} finite={bool(torch.isfinite(out).all())}"
+              f"  fp32-vs-fp64 L1={(out.double() - out64).abs().mean():.3e}")
         # noise is regenerated from the seed by the tests (1 MB at N=50); keep a checksum instead
         keep = {k: v for k, v in inp.items() if k != "noise"}
-        save(f"loop_full_N{n}", **keep, out=out, noise_abs_sum=inp["noise"].double().abs().sum(),
+        save(f"loop_full_N{n}", **keep, out=out, out_fp64=out64, noise_abs_sum=inp["noise"].double().abs().sum(),
              w_text=1.0, w_spk=1.0)
 
     # ---- G7 loss_t + gradients ------------------------------------------------------------------

@@ -102,13 +102,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
   };
 
-  f32x16 acc[2][2];
+  // Two-level accumulation: the MFMA chain (an exact fp32 fma chain) runs over kFlushK = 128 K-elements, then is
+  // folded into `total`.  A single chain over K = 9*Cin (up to 18,432) would carry ~0.2*sqrt(K) ulp of rounding
+  // error (19 ulp at K = 9,216); chunks of ~sqrt(K) bring it to ~3 ulp, on par with a blocked CPU sgemm.
+  constexpr int kFlushSteps = 128 / BK;
+  f32x16 acc[2][2], total[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; total[i][j][r] = 0.f; }
+  int since_flush = 0;
 
   int tap_n = 0, ch_n = 0;
   setup_tap(0);
@@ -144,8 +149,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       stage((step + 1) & 1);
       if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
     }
+    if (++since_flush == kFlushSteps) {
+      since_flush = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          total[i][j] += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
     __syncthreads();
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
 
   // ---- epilogue: C/D layout of the 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
   const bool dense = (a.ostep == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Hs == a.Hout && a.Ws == a.Wout);

@@ -85,6 +85,21 @@ struct us_decoder {
   int n_resnets = 0;
   std::string err;
 
+  // ---- sampled kernel timing (bench.py roofline leg) ----
+  struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = conv_igemm launch, 1 = whole evaluation
+  bool prof_enabled = false;
+  bool prof_active = false;           // true while the sampled evaluation is being enqueued
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_conv_ms = 0, prof_conv_flops = 0, prof_eval_ms = 0;
+  long long prof_conv_launches = 0, prof_evals = 0;
+  hipEvent_t prof_event() {
+    if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+
   int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -329,6 +344,22 @@ ConvArgs base_args(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int H
   return a;
 }
 
+// every implicit-GEMM launch goes through here so the sampled evaluation can bracket it with HIP events
+hipError_t run_conv(EvalCtx& e, const ConvArgs& a) {
+  us_decoder* h = e.h;
+  if (!h->prof_active) return launch_conv_igemm(a, e.s);
+  us_decoder::ProfRec r;
+  r.a = h->prof_event();
+  r.b = h->prof_event();
+  r.kind = 0;
+  r.flops = 2.0 * a.B * (double)a.Hs * a.Ws * a.Cout * (double)a.Cin * a.ntaps;
+  (void)hipEventRecord(r.a, e.s);
+  hipError_t err = launch_conv_igemm(a, e.s);
+  (void)hipEventRecord(r.b, e.s);
+  h->prof_pending.push_back(r);
+  return err;
+}
+
 hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
@@ -341,7 +372,7 @@ hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
     }
   set_mask(e, a, level);
   a.stats = stats;
-  return launch_conv_igemm(a, e.s);
+  return run_conv(e, a);
 }
 
 hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, bool masked, float* out, int out_ld,
@@ -353,7 +384,7 @@ hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
   if (masked) set_mask(e, a, level);
   a.add = add; a.add_ld = add_ld; a.alpha = alpha;
   if (wt_override) { a.wt = wt_override; a.wt_bstride = wt_bstride; a.bias = bias_override; }
-  return launch_conv_igemm(a, e.s);
+  return run_conv(e, a);
 }
 
 hipError_t conv_down(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld) {
@@ -368,7 +399,7 @@ hipError_t conv_down(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int
       a.wtap[ky * 3 + kx] = (unsigned char)(ky * 3 + kx);
     }
   set_mask(e, a, level);
-  return launch_conv_igemm(a, e.s);
+  return run_conv(e, a);
 }
 
 // ConvTranspose2d(k=4, s=2, p=1): output row oy = 2*iy - 1 + ky.  Output phase py = oy & 1 receives exactly two
@@ -389,7 +420,7 @@ hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
           a.wtap[i * 2 + j] = (unsigned char)(KY[py][i] * 4 + KY[px][j]);
         }
       set_mask(e, a, level);
-      hipError_t err = launch_conv_igemm(a, e.s);
+      hipError_t err = run_conv(e, a);
       if (err != hipSuccess) return err;
     }
   return hipSuccess;
@@ -477,8 +508,30 @@ hipError_t time_embedding(EvalCtx& e, const float* t, const float* spk) {
 }
 
 // x: [Bx][F][T]; mu: [Bmu][F][T]; items b' < n_text_uncond use text_uncon instead of mu; spk: [Bp][S]; t: [Bp]
+hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* mu, int Bmu, int n_text_uncond, const float* t,
+                               const float* spk, float* out);
+
+// `sample` marks the evaluation whose launches are bracketed with events when profiling is enabled
 hipError_t estimator_eval(EvalCtx& e, const float* x, int Bx, const float* mu, int Bmu, int n_text_uncond, const float* t,
-                          const float* spk, float* out) {
+                          const float* spk, float* out, bool sample = false) {
+  us_decoder* h = e.h;
+  if (!(h->prof_enabled && sample)) return estimator_eval_impl(e, x, Bx, mu, Bmu, n_text_uncond, t, spk, out);
+  us_decoder::ProfRec r;
+  r.a = h->prof_event();
+  r.b = h->prof_event();
+  r.kind = 1;
+  r.flops = 0;
+  (void)hipEventRecord(r.a, e.s);
+  h->prof_active = true;
+  hipError_t err = estimator_eval_impl(e, x, Bx, mu, Bmu, n_text_uncond, t, spk, out);
+  h->prof_active = false;
+  (void)hipEventRecord(r.b, e.s);
+  h->prof_pending.push_back(r);
+  return err;
+}
+
+hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* mu, int Bmu, int n_text_uncond, const float* t,
+                               const float* spk, float* out) {
   us_decoder* h = e.h;
   Buffers& b = *e.b;
   const int L = h->cfg.n_mults, F = h->cfg.n_feats, T = e.T;
@@ -603,6 +656,8 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
   for (auto& s : h->slots) if (s->buf.p) (void)hipFree(s->buf.p);
+  for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;
   return US_OK;
 }
@@ -673,7 +728,7 @@ int us_estimator_forward(us_handle h, const float* x, const float* mask, const f
   Buffers b;
   plan(h, A, Bp, T, b);
   EvalCtx e{h, static_cast<hipStream_t>(stream), &b, Bp, T, mask, Bp};
-  US_HIP(h, estimator_eval(e, x, Bp, mu, Bp, 0, t, spk, out));
+  US_HIP(h, estimator_eval(e, x, Bp, mu, Bp, 0, t, spk, out, true));
   return US_OK;
 }
 
@@ -775,7 +830,7 @@ int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const f
     for (int i = 0; i < N; ++i) {
       const float* c = coef_host + (size_t)i * 8;
       US_HIP(h, launch_fill(tbuf, c[6], Bp, s));
-      US_HIP(h, estimator_eval(e, xt, mb, cond_b, mb, n_text_uncond, tbuf, spk_cfg, score));
+      US_HIP(h, estimator_eval(e, xt, mb, cond_b, mb, n_text_uncond, tbuf, spk_cfg, score, i == N / 2));
       SamplerArgs sa;
       memset(&sa, 0, sizeof sa);
       sa.xt = xt; sa.score = score; sa.mask = mask_b; sa.out = xt;
@@ -831,6 +886,34 @@ double us_estimator_flops(us_handle h, int T) {
   fl += 2.0 * (double)h->cfg.dim * 4 * h->cfg.dim * 2;       // time MLP
   (void)L;
   return fl;
+}
+
+int us_profile_enable(us_handle h, int enable) {
+  if (!h) return US_EINVAL;
+  h->prof_enabled = enable != 0;
+  return US_OK;
+}
+
+int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* conv_launches, double* eval_ms, int64_t* evals,
+                    int reset) {
+  if (!h) return US_EINVAL;
+  for (auto& r : h->prof_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+      return h->fail(US_EHIP, "profile event read failed (device not synchronised?)");
+    if (r.kind == 0) { h->prof_conv_ms += ms; h->prof_conv_flops += r.flops; h->prof_conv_launches++; }
+    else { h->prof_eval_ms += ms; h->prof_evals++; }
+    h->prof_pool.push_back(r.a);
+    h->prof_pool.push_back(r.b);
+  }
+  h->prof_pending.clear();
+  if (conv_ms) *conv_ms = h->prof_conv_ms;
+  if (conv_flops) *conv_flops = h->prof_conv_flops;
+  if (conv_launches) *conv_launches = h->prof_conv_launches;
+  if (eval_ms) *eval_ms = h->prof_eval_ms;
+  if (evals) *evals = h->prof_evals;
+  if (reset) { h->prof_conv_ms = h->prof_conv_flops = h->prof_eval_ms = 0; h->prof_conv_launches = h->prof_evals = 0; }
+  return US_OK;
 }
 
 const char* us_last_error(us_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }

@@ -173,7 +173,15 @@ def n_params(cfg: DecoderConfig) -> int:
 # ---------------------------------------------------------------------------------------------
 # Synthetic weights
 # ---------------------------------------------------------------------------------------------
-REZERO_G = 0.02   # g=0.02 keeps the untrained 50-step loop finite; 0.1/0.5 overflow
+# Conditioning of the untrained sampler (measured with the fp64 oracle, full size, T=64, N=50, text+spk CFG): the
+# un-normalised linear attention is quadratic in its input, and with g=0.02 and default-scale to_qkv weights the
+# residual loop x <- x + g*attn(x) turns chaotic once |x| ~ 100 (steps 30-45): a 1e-7 relative perturbation of z
+# grows to 1e-3 relative (0.18 absolute), which is also the reference's own fp32-vs-fp64 distance, so no fp32
+# implementation can be pinned to 1e-3 there.  Quartering the attention branch gain (either g/4 or to_qkv/2)
+# removes the growth entirely (relative perturbation stays 7e-8 for all 50 steps); the recipe uses g=0.01 and
+# to_qkv*0.5 (8x margin) while keeping attention large enough that an error in it is far above test tolerances.
+REZERO_G = 0.01
+QKV_SCALE = 0.5
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:
@@ -196,7 +204,8 @@ def synthetic_state_dict(cfg: DecoderConfig, seed: int = 0) -> "OrderedDict[str,
 
     Scale follows torch's default conv/linear init (uniform(+-1/sqrt(fan_in)) for weight and bias);
     GroupNorm affine is perturbed around (1, 0) so the affine path is exercised; every Rezero gain is
-    REZERO_G and the two learned unconditional embeddings are non-zero (a fresh reference module has
+    REZERO_G, to_qkv weights are scaled by QKV_SCALE (see the conditioning note above) and the two learned
+    unconditional embeddings are non-zero (a fresh reference module has
     g = 0 and spk_uncon = 0, which disables attention and makes `spk_uncon / spk_uncon.norm()` NaN,
     `unitspeech/unitspeech.py:40,231,358`).
     """
@@ -219,6 +228,8 @@ def synthetic_state_dict(cfg: DecoderConfig, seed: int = 0) -> "OrderedDict[str,
             else:
                 fan_in = int(np.prod(shape[1:]))
             out[name] = _uniform(seed, name, shape, 1.0 / np.sqrt(fan_in))
+            if name.endswith("to_qkv.weight"):
+                out[name] = (out[name] * np.float32(QKV_SCALE)).astype(np.float32)
         elif name.endswith(".bias"):
             wshape = param_shapes(cfg)[name[:-4] + "weight"]
             if name.endswith(".3.conv.bias") and len(wshape) == 4 and wshape[2] == 4:
