@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Join a rocprofv3 kernel trace of bench.py with the decoder's conv launch schedule: per-launch TFLOP/s.
+
+usage: tools/analyze_trace.py <kernel_trace.csv> [--frames 1024] [--bp 3]
+The launch order below mirrors estimator_eval() in unitspeech_amd/csrc/decoder.hip."""
+import argparse
+import collections
+import csv
+import sys
+
+ap = argparse.ArgumentParser()
+ap.add_argument("trace")
+ap.add_argument("--frames", type=int, default=1024)
+ap.add_argument("--bp", type=int, default=3)
+ap.add_argument("--dim", type=int, default=128)
+a = ap.parse_args()
+
+F, T, BP = 80, a.frames, a.bp
+C = [a.dim * m for m in (1, 2, 4, 8)]
+L = 4
+
+
+def npx(l):
+    return (F >> l) * (T >> l)
+
+
+seq = []
+
+
+def conv(name, l_out_pixels, cin, cout, taps):
+    seq.append((name, 2.0 * BP * l_out_pixels * cin * cout * taps, l_out_pixels, cin, cout, taps))
+
+
+def resnet(name, l, cin, cout, first=False):
+    if not first:
+        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9)
+    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9)
+    if cin != cout and not first:
+        conv(f"{name}.res 1x1 {cin}->{cout} L{l}", npx(l), cin, cout, 1)
+
+
+def attn(name, l, c):
+    conv(f"{name}.qkv 1x1 {c}->384 L{l}", npx(l), c, 384, 1)
+    conv(f"{name}.out 1x1 128->{c} L{l}", npx(l), 128, c, 1)
+
+
+for l in range(L):
+    cin = 2 if l == 0 else C[l - 1]
+    resnet(f"downs.{l}.r1", l, cin, C[l], first=(l == 0))
+    resnet(f"downs.{l}.r2", l, C[l], C[l])
+    attn(f"downs.{l}.attn", l, C[l])
+    if l < L - 1:
+        conv(f"downs.{l}.down 3x3s2 {C[l]} L{l}->L{l+1}", npx(l + 1), C[l], C[l], 9)
+resnet("mid1", L - 1, C[-1], C[-1])
+attn("mid.attn", L - 1, C[-1])
+resnet("mid2", L - 1, C[-1], C[-1])
+for u in range(L - 1):
+    l = L - 1 - u
+    co = C[l - 1]
+    resnet(f"ups.{u}.r1", l, 2 * C[l], co)
+    resnet(f"ups.{u}.r2", l, co, co)
+    attn(f"ups.{u}.attn", l, co)
+    for ph in range(4):
+        conv(f"ups.{u}.up phase{ph} {co} L{l}->L{l-1}", npx(l), co, co, 4)
+conv("final 3x3 128->128 L0", npx(0), C[0], C[0], 9)
+
+rows = [r for r in csv.DictReader(open(a.trace)) if "conv_igemm" in r["Kernel_Name"]]
+n = len(seq)
+assert len(rows) % n == 0, (len(rows), n)
+evals = len(rows) // n
+dur = collections.defaultdict(list)
+for i, r in enumerate(rows):
+    dur[i % n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print(f"{evals} evaluations x {n} conv launches")
+tot_t = tot_f = 0.0
+print(f"{'launch':44s} {'GFLOP':>8s} {'us':>8s} {'TF/s':>7s} {'share':>6s}  WGs")
+total_time = sum(sum(v) / len(v) for v in dur.values())
+for i, (name, fl, px, cin, cout, taps) in enumerate(seq):
+    t = sum(dur[i]) / len(dur[i]) * 1e-9
+    tot_t += t
+    tot_f += fl
+    wgs = ((px + 127) // 128) * ((cout + 127) // 128) * BP
+    print(f"{name:44s} {fl/1e9:8.2f} {t*1e6:8.1f} {fl/t/1e12:7.1f} {t*1e9/total_time:6.3f}  {wgs}")
+print(f"TOTAL conv: {tot_f/1e9:.1f} GFLOP in {tot_t*1e3:.3f} ms = {tot_f/tot_t/1e12:.1f} TFLOP/s")

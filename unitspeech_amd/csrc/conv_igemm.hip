@@ -6,12 +6,19 @@
 //   of a 2x2 tap set).
 // GEMM view: M = output pixels of one item (flattened sub-grid), N = Cout, K = taps * Cin.
 //
-// Tile: 128 (pixels) x 128 (channels) per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA
-// 32x32 blocks (64 accumulator VGPRs).  K advances in chunks of BK input channels of one tap; A (activation
-// rows, gathered per tap with zero padding and the frame mask applied on the way in) and B (weights, pre-packed
-// so a tile is one contiguous 128*BK slab) are staged global -> registers -> LDS, double-buffered, one barrier
-// per chunk.  LDS rows are padded to BK+4 floats: the ds_read_b128 fragment reads (lane = row, 4 consecutive k)
-// are then conflict-free (row*(BK+4)/4 mod 16 is a permutation of 0..15 over any 16 consecutive rows).
+// Workgroup = 256 threads = 4 waves as 2 (M) x 2 (N); tile TM x 128 with TM = 128 (wave tile 64x64 = 2x2 MFMA 32x32
+// blocks) or TM = 64 (wave tile 32x64) for launches that would otherwise leave CUs idle.  K advances in chunks of BK
+// input channels of one tap.  Both operands go global -> LDS directly (global_load_lds_dwordx4, no staging
+// registers, no ds_write): the A rows are gathered per tap through per-lane source addresses (out-of-image taps
+// read a zero page), the B rows come from weights pre-packed as [tap][Cin/BK][Cout][BK] so a tile row is one
+// contiguous BK*4-byte line.  The LDS image is lane-linear as the DMA requires; bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE side (lane `pos` of a row
+// fetches 16-byte chunk pos ^ swz(row)) and again on the read side, swz(row) = (row / (64/BK)) % (BK/4): the 16
+// rows of a ds_read_b128 lane group then hit 16 distinct 16-byte slots of the 256-byte bank window.
+// Two LDS buffers; the DMA for chunk s+1 is issued before the MFMAs of chunk s; one barrier per chunk.
+//
+// Inputs are expected to be already multiplied by the frame mask by their producer (every consumer of such a
+// tensor in the reference applies `x * mask`, :54,:74); the epilogue can apply the mask to what it stores.
 // k-index convention inside an 8-channel sub-step: lane half hh supplies channels 4*hh+j to MFMA j (j=0..3) on
 // BOTH operands, so the pairs (j, 4+j) are summed by instruction j; the K-sum is complete, only its order differs.
 #include "kernels.h"
@@ -21,138 +28,137 @@ namespace us {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 128, TN = 128;
+constexpr int TN = 128;
 
-template <int BK>
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+template <int BK, int WM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int LD = BK + 4;
-  constexpr int QPR = BK / 4;     // float4 per tile row
-  constexpr int RPP = 256 / QPR;  // rows per pass
-  constexpr int NP = TM / RPP;    // passes
-  constexpr int TILE = TM * LD;   // floats per operand tile
+  constexpr int TM = 2 * WM;         // rows (pixels) per workgroup
+  constexpr int MB = WM / 32;        // 32-row MFMA blocks per wave along M
+  constexpr int CPR = BK / 4;        // 16-byte chunks per tile row
+  constexpr int RPI = 64 / CPR;      // rows covered by one wave-wide DMA instruction
+  constexpr int IA = TM / RPI / 4;   // DMA instructions per wave for the A tile
+  constexpr int IB = TN / RPI / 4;   // ... for the B tile
+  constexpr int SWZ_DIV = 64 / BK;   // rows per 256-byte bank window
+  constexpr int BUF = (TM + TN) * BK;  // floats per LDS buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z;
   const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
   const int Ms = a.Hs * a.Ws;
-  const int q = tid % QPR, r0 = tid / QPR;
   const int nchunk = a.Cin / BK;
   const int S = a.ntaps * nchunk;
 
-  int my[NP], mx[NP];
-  bool mv[NP];
+  // ---- DMA source bookkeeping: this lane feeds LDS position (row = rbase + lane/CPR, chunk slot = lane%CPR) ----
+  const int lrow = lane / CPR, lpos = lane % CPR;
+  int my[IA], mx[IA], achunk[IA];
+  bool mv[IA];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    int m = m0 + r0 + j * RPP;
+  for (int j = 0; j < IA; ++j) {
+    const int r = (wave * IA + j) * RPI + lrow;      // row inside the A tile
+    const int m = m0 + r;
     mv[j] = m < Ms;
-    int mc = mv[j] ? m : 0;
+    const int mc = mv[j] ? m : 0;
     my[j] = mc / a.Ws;
     mx[j] = mc - my[j] * a.Ws;
+    achunk[j] = (lpos ^ ((r / SWZ_DIV) % CPR)) * 4;   // source chunk (floats) for this LDS slot
   }
-  // B rows (output channels) this thread stages; clamped for memory safety (columns >= Cout are never stored)
-  int brow[NP];
+  long long boff[IB];   // float offset of this lane's B source inside a [Cout][BK] slab
 #pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    int n = n0 + r0 + j * RPP;
-    brow[j] = n < a.Cout ? n : a.Cout - 1;
+  for (int j = 0; j < IB; ++j) {
+    const int r = (wave * IB + j) * RPI + lrow;
+    int n = n0 + r;
+    n = n < a.Cout ? n : a.Cout - 1;                  // clamp: columns >= Cout are never stored
+    boff[j] = (long long)n * BK + (lpos ^ ((r / SWZ_DIV) % CPR)) * 4;
   }
   const float* wt_b = a.wt + (long long)b * a.wt_bstride;
   const float* in_b = a.in + (long long)b * a.Hin * a.Win * a.in_ld;
-  const float* mask_b = a.mask ? a.mask + (long long)(b % a.mask_bmod) * a.mask_ld : nullptr;
 
-  const float* aptr[NP];
-  float amul[NP];
-  bool aok[NP];
+  const float* aptr[IA];
   const float* wtap = nullptr;
-
   auto setup_tap = [&](int tap) {
-    const int dy = a.dy[tap], dx = a.dx[tap];
+    const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
+    const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
+    const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      int iy = my[j] * a.istride + dy, ix = mx[j] * a.istride + dx;
-      bool ok = mv[j] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-      aok[j] = ok;
-      int iyc = ok ? iy : 0, ixc = ok ? ix : 0;
-      aptr[j] = in_b + ((long long)iyc * a.Win + ixc) * a.in_ld + q * 4;
-      amul[j] = mask_b ? mask_b[ixc * a.mask_step] : 1.f;
+    for (int j = 0; j < IA; ++j) {
+      const int iy = my[j] * a.istride + dy, ix = mx[j] * a.istride + dx;
+      const bool ok = mv[j] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      const float* p = in_b + ((long long)iy * a.Win + ix) * a.in_ld;
+      aptr[j] = (ok ? p : a.zeros) + achunk[j];       // zero page is >= Cin floats long
     }
-    wtap = wt_b + (long long)a.wtap[tap] * nchunk * a.Cout * BK;
+    wtap = wt_b + (long long)wt_i * nchunk * a.Cout * BK;
+  };
+  auto dma = [&](int ch, int buf) {
+    float* As = smem + buf * BUF;
+    float* Bs = As + TM * BK;
+#pragma unroll
+    for (int j = 0; j < IA; ++j) glds16(aptr[j] + ch * BK, As + (wave * IA + j) * RPI * BK);
+    const float* wb = wtap + (long long)ch * a.Cout * BK;
+#pragma unroll
+    for (int j = 0; j < IB; ++j) glds16(wb + boff[j], Bs + (wave * IB + j) * RPI * BK);
   };
 
-  f32x4 ra[NP], rb[NP];
-  auto prefetch = [&](int ch) {
-#pragma unroll
-    for (int j = 0; j < NP; ++j) ra[j] = *reinterpret_cast<const f32x4*>(aptr[j] + ch * BK);
-    const float* wb = wtap + (long long)ch * a.Cout * BK + q * 4;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wb + (long long)brow[j] * BK);
-  };
-  auto stage = [&](int buf) {
-    float* As = smem + buf * 2 * TILE;
-    float* Bs = As + TILE;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      f32x4 v = ra[j] * amul[j];
-      if (!aok[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(As + (r0 + j * RPP) * LD + q * 4) = v;
-      *reinterpret_cast<f32x4*>(Bs + (r0 + j * RPP) * LD + q * 4) = rb[j];
-    }
-  };
-
-  // Two-level accumulation: the MFMA chain (an exact fp32 fma chain) runs over kFlushK = 128 K-elements, then is
-  // folded into `total`.  A single chain over K = 9*Cin (up to 18,432) would carry ~0.2*sqrt(K) ulp of rounding
-  // error (19 ulp at K = 9,216); chunks of ~sqrt(K) bring it to ~3 ulp, on par with a blocked CPU sgemm.
+  // Two-level accumulation: the MFMA chain (an exact fp32 fma chain) runs over 128 K-elements, then is folded into
+  // `total`.  A single chain over K = 9*Cin (up to 18,432) would carry ~0.2*sqrt(K) ulp of rounding error (19 ulp
+  // at K = 9,216); chunks of ~sqrt(K) bring it to ~3 ulp, on par with a blocked CPU sgemm.
   constexpr int kFlushSteps = 128 / BK;
-  f32x16 acc[2][2], total[2][2];
+  f32x16 acc[MB][2], total[MB][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; total[i][j][r] = 0.f; }
   int since_flush = 0;
 
+  // fragment read offsets (floats): row R, 16-byte chunk (2s+hh) ^ swz(R); swz only depends on the lane
+  const int sw = (l32 / SWZ_DIV) % CPR;
+  const int a_row = (wm * WM + l32) * BK;
+  const int b_row = TM * BK + (wn * 64 + l32) * BK;
+
   int tap_n = 0, ch_n = 0;
   setup_tap(0);
-  prefetch(0);
-  stage(0);
-  __syncthreads();
+  dma(0, 0);
   if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+  __syncthreads();
 
   for (int step = 0; step < S; ++step) {
     const bool has_next = step + 1 < S;
     if (has_next) {
       if (ch_n == 0) setup_tap(tap_n);
-      prefetch(ch_n);
+      dma(ch_n, (step + 1) & 1);
+      if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
     }
-    const float* As = smem + (step & 1) * 2 * TILE + (wm * 64 + l32) * LD + hh * 4;
-    const float* Bs = smem + (step & 1) * 2 * TILE + TILE + (wn * 64 + l32) * LD + hh * 4;
+    const float* base = smem + (step & 1) * BUF;
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
-      f32x4 af[2], bf[2];
-      af[0] = *reinterpret_cast<const f32x4*>(As + s * 8);
-      af[1] = *reinterpret_cast<const f32x4*>(As + 32 * LD + s * 8);
-      bf[0] = *reinterpret_cast<const f32x4*>(Bs + s * 8);
-      bf[1] = *reinterpret_cast<const f32x4*>(Bs + 32 * LD + s * 8);
+      const int co = ((2 * s + hh) ^ sw) * 4;
+      f32x4 af[MB], bf[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][j], bf[0][j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][j], bf[1][j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][j], bf[0][j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][j], bf[1][j], acc[1][1], 0, 0, 0);
-      }
-    }
-    if (has_next) {
-      stage((step + 1) & 1);
-      if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+      for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + co);
+      bf[0] = *reinterpret_cast<const f32x4*>(base + b_row + co);
+      bf[1] = *reinterpret_cast<const f32x4*>(base + b_row + 32 * BK + co);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[0][j], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[1][j], acc[i][1], 0, 0, 0);
+        }
     }
     if (++since_flush == kFlushSteps) {
       since_flush = 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           total[i][j] += acc[i][j];
@@ -160,10 +166,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
     }
-    __syncthreads();
+    __syncthreads();   // drains this wave's DMA (vmcnt(0)) and orders every wave's reads before the next overwrite
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
 
@@ -172,37 +178,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const float alpha = a.alpha ? *a.alpha : 1.f;
   float* out_b = a.out + (long long)b * a.Hout * a.Wout * a.out_ld;
   const float* add_b = a.add ? a.add + (long long)b * a.Hout * a.Wout * a.add_ld : nullptr;
+  const float* om_b = a.omask ? a.omask + (long long)(b % a.omask_bmod) * a.omask_ld : nullptr;
   float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = n0 + wn * 64 + nb * 32 + l32;
-    const bool nv = n < a.Cout;
-    const float bias = (a.bias && nv) ? a.bias[n] : 0.f;
+  for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * WM + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (m < Ms) {
+        const int yy = m / a.Ws, xx = m - yy * a.Ws;
+        const int ox = a.ox0 + xx * a.ostep;
+        const long long pix = dense ? (long long)m : (long long)(a.oy0 + yy * a.ostep) * a.Wout + ox;
+        const float om = om_b ? om_b[ox * a.omask_step] : 1.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m < Ms && nv) {
-          long long pix;
-          if (dense) {
-            pix = m;
-          } else {
-            int yy = m / a.Ws, xx = m - yy * a.Ws;
-            pix = (long long)(a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep;
+        for (int nb = 0; nb < 2; ++nb) {
+          const int n = n0 + wn * 64 + nb * 32 + l32;
+          if (n < a.Cout) {
+            float v = acc[mb][nb][r] + (a.bias ? a.bias[n] : 0.f);
+            gsum[nb] += v;
+            gsq[nb] += v * v;
+            v *= alpha;
+            if (add_b) v += add_b[pix * a.add_ld + n];
+            out_b[pix * a.out_ld + n] = v * om;
           }
-          float v = acc[mb][nb][r] + bias;
-          gsum[nb] += v;
-          gsq[nb] += v * v;
-          v *= alpha;
-          if (add_b) v += add_b[pix * a.add_ld + n];
-          out_b[pix * a.out_ld + n] = v;
         }
       }
     }
   }
   if (a.stats) {
-    // GroupNorm(8) partial sums of the stored (pre-alpha/add) values; Cout/8 is a power of two (host-checked)
+    // GroupNorm(8) partial sums of the conv output (pre-alpha/add/mask); Cout/8 is a power of two (host-checked)
     const int cg = a.Cout / kGroups;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -224,29 +228,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-static size_t lds_bytes(int bk) { return (size_t)2 * 2 * TM * (bk + 4) * sizeof(float); }
+static size_t lds_bytes(int bk, int tm) { return (size_t)2 * (tm + TN) * bk * sizeof(float); }
+
+template <int BK, int WM>
+static hipError_t set_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, WM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds_bytes(BK, 2 * WM));
+}
 
 hipError_t conv_igemm_init() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<32>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(32));
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<16>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(16));
+  hipError_t e;
+  if ((e = set_attr<32, 64>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 32>()) != hipSuccess) return e;
+  if ((e = set_attr<16, 64>()) != hipSuccess) return e;
+  return set_attr<16, 32>();
 }
+
+static int g_tm64_threshold = -1;
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
   if ((a.bk != 16 && a.bk != 32) || a.Cin % a.bk != 0 || a.ntaps < 1 || a.ntaps > kMaxTaps) return hipErrorInvalidValue;
-  if (a.in_ld % 4 != 0) return hipErrorInvalidValue;   // 16-byte vector loads of the activation rows
+  if (a.in_ld % 4 != 0 || !a.zeros) return hipErrorInvalidValue;   // 16-byte DMA pieces of the activation rows
   if (a.stats) {
     int cg = a.Cout / kGroups;
     if (a.Cout % kGroups != 0 || (cg & (cg - 1)) != 0) return hipErrorInvalidValue;
   }
-  dim3 grid((a.Hs * a.Ws + TM - 1) / TM, (a.Cout + TN - 1) / TN, a.B);
-  if (a.bk == 32)
-    hipLaunchKernelGGL(conv_igemm_kernel<32>, grid, dim3(256), lds_bytes(32), s, a);
+  if (g_tm64_threshold < 0) {
+    const char* e = getenv("US_TM64_THRESHOLD");
+    g_tm64_threshold = e ? atoi(e) : 512;
+  }
+  const int Ms = a.Hs * a.Ws;
+  const int nt = (a.Cout + TN - 1) / TN;
+  int tm = a.tm;
+  if (tm == 0) {
+    const long long wgs128 = (long long)((Ms + 127) / 128) * nt * a.B;
+    tm = wgs128 < g_tm64_threshold ? 64 : 128;
+  }
+  dim3 grid((Ms + tm - 1) / tm, nt, a.B);
+  const size_t lds = lds_bytes(a.bk, tm);
+  if (a.bk == 32 && tm == 128)
+    hipLaunchKernelGGL((conv_igemm_kernel<32, 64>), grid, dim3(256), lds, s, a);
+  else if (a.bk == 32)
+    hipLaunchKernelGGL((conv_igemm_kernel<32, 32>), grid, dim3(256), lds, s, a);
+  else if (tm == 128)
+    hipLaunchKernelGGL((conv_igemm_kernel<16, 64>), grid, dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL(conv_igemm_kernel<16>, grid, dim3(256), lds_bytes(16), s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<16, 32>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

@@ -83,6 +83,7 @@ struct us_decoder {
   Slot *final_g, *final_b, *final_w1, *final_b1;
   Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
   int n_resnets = 0;
+  float* zeros = nullptr;   // zero page read by out-of-image convolution taps
   std::string err;
 
   // ---- sampled kernel timing (bench.py roofline leg) ----
@@ -322,11 +323,12 @@ double* next_stats(EvalCtx& e) {
   return p;
 }
 
-void set_mask(EvalCtx& e, ConvArgs& a, int level_in) {
-  a.mask = e.mask;
-  a.mask_ld = e.T;
-  a.mask_step = 1 << level_in;
-  a.mask_bmod = e.Bm;
+// frame mask of the OUTPUT tensor (at `level_out` resolution) applied by the epilogue
+void set_omask(EvalCtx& e, ConvArgs& a, int level_out) {
+  a.omask = e.mask;
+  a.omask_ld = e.T;
+  a.omask_step = 1 << level_out;
+  a.omask_bmod = e.Bm;
 }
 
 ConvArgs base_args(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int Hin, int Win, float* out, int out_ld, int Hout,
@@ -340,7 +342,8 @@ ConvArgs base_args(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int H
   a.B = e.Bp; a.Hin = Hin; a.Win = Win; a.Cin = w.cin; a.Hout = Hout; a.Wout = Wout; a.Cout = w.cout;
   a.Hs = Hout; a.Ws = Wout; a.ostep = 1; a.istride = 1;
   a.bk = w.w->bk;
-  a.mask_bmod = 1;
+  a.omask_bmod = 1;
+  a.zeros = e.h->zeros;
   return a;
 }
 
@@ -365,23 +368,19 @@ hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
   a.ntaps = 9;
   for (int ky = 0; ky < 3; ++ky)
-    for (int kx = 0; kx < 3; ++kx) {
-      a.dy[ky * 3 + kx] = (signed char)(ky - 1);
-      a.dx[ky * 3 + kx] = (signed char)(kx - 1);
-      a.wtap[ky * 3 + kx] = (unsigned char)(ky * 3 + kx);
-    }
-  set_mask(e, a, level);
+    for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx);
   a.stats = stats;
   return run_conv(e, a);
 }
 
-hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, bool masked, float* out, int out_ld,
+hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, bool mask_out, float* out, int out_ld,
                    const float* add, int add_ld, const float* alpha, const float* wt_override, long long wt_bstride,
                    const float* bias_override) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
   a.ntaps = 1;
-  if (masked) set_mask(e, a, level);
+  a.set_tap(0, 0, 0, 0);
+  if (mask_out) set_omask(e, a, level);
   a.add = add; a.add_ld = add_ld; a.alpha = alpha;
   if (wt_override) { a.wt = wt_override; a.wt_bstride = wt_bstride; a.bias = bias_override; }
   return run_conv(e, a);
@@ -393,12 +392,8 @@ hipError_t conv_down(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int
   a.ntaps = 9;
   a.istride = 2;
   for (int ky = 0; ky < 3; ++ky)
-    for (int kx = 0; kx < 3; ++kx) {
-      a.dy[ky * 3 + kx] = (signed char)(ky - 1);
-      a.dx[ky * 3 + kx] = (signed char)(kx - 1);
-      a.wtap[ky * 3 + kx] = (unsigned char)(ky * 3 + kx);
-    }
-  set_mask(e, a, level);
+    for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx);
+  set_omask(e, a, level + 1);     // consumers of the downsampled tensor mask it (next ResnetBlock, :54,:74)
   return run_conv(e, a);
 }
 
@@ -414,12 +409,8 @@ hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
       a.Hs = H; a.Ws = W; a.ostep = 2; a.oy0 = py; a.ox0 = px;
       a.ntaps = 4;
       for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j) {
-          a.dy[i * 2 + j] = (signed char)DY[py][i];
-          a.dx[i * 2 + j] = (signed char)DY[px][j];
-          a.wtap[i * 2 + j] = (unsigned char)(KY[py][i] * 4 + KY[px][j]);
-        }
-      set_mask(e, a, level);
+        for (int j = 0; j < 2; ++j) a.set_tap(i * 2 + j, DY[py][i], DY[px][j], KY[py][i] * 4 + KY[px][j]);
+      set_omask(e, a, level - 1);   // the upsampled tensor is only consumed masked (next level's ResnetBlock / final Block)
       hipError_t err = run_conv(e, a);
       if (err != hipSuccess) return err;
     }
@@ -427,7 +418,7 @@ hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
 }
 
 hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* stats, const Slot* g, const Slot* bta,
-                    const float* temb, const float* res, int res_ld, bool res_masked, float* out, int out_ld) {
+                    const float* temb, const float* res, int res_ld, bool res_masked, bool post_mask, float* out, int out_ld) {
   GnApplyArgs a;
   memset(&a, 0, sizeof a);
   a.y = y; a.y_ld = C;
@@ -436,6 +427,7 @@ hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* 
   a.mask = e.mask; a.mask_ld = e.T; a.mask_step = 1 << level; a.mask_bmod = e.Bm;
   a.temb = temb; a.temb_ld = C;
   a.res = res; a.res_ld = res_ld; a.res_masked = res_masked ? 1 : 0;
+  a.post_mask = post_mask ? 1 : 0;
   a.out = out; a.out_ld = out_ld;
   a.B = e.Bp; a.H = e.h->cfg.n_feats >> level; a.W = e.T >> level; a.C = C;
   return launch_gn_apply(a, e.s);
@@ -447,8 +439,10 @@ hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* 
     if (_e != hipSuccess) return _e;      \
   } while (0)
 
-// ResnetBlock (unitspeech/unitspeech.py:58-75)
-hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, float* out, int out_ld) {
+// ResnetBlock (unitspeech/unitspeech.py:58-75).  `in` must already be masked.  mask_out: the result is only consumed
+// through `x * mask` (next ResnetBlock / concat), so the mask is applied to what is stored; false when the consumer
+// is the attention, which reads the raw tensor (padded frames included, :91).
+hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, float* out, int out_ld, bool mask_out) {
   Buffers& b = *e.b;
   const int l = r.level;
   float* S1 = b.S1[l];
@@ -457,13 +451,14 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
   double* st1 = next_stats(e);
   double* st2 = next_stats(e);
   CK(conv3x3(e, r.c1, in, in_ld, l, S1, r.cout, st1));
-  CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, S1, r.cout));
+  // block1 output + time embedding, pre-masked for block2's `x * mask` (:54)
+  CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, true, S1, r.cout));
   CK(conv3x3(e, r.c2, S1, r.cout, l, S2, r.cout, st2));
   if (r.has_res) {
-    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, nullptr, 0, false, out, out_ld));
-    CK(conv1x1(e, r.res, in, in_ld, l, true, out, out_ld, out, out_ld, nullptr, nullptr, 0, nullptr));
+    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, nullptr, 0, false, false, out, out_ld));
+    CK(conv1x1(e, r.res, in, in_ld, l, mask_out, out, out_ld, out, out_ld, nullptr, nullptr, 0, nullptr));
   } else {
-    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, in, in_ld, true, out, out_ld));
+    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, in, in_ld, false, mask_out, out, out_ld));
   }
   return hipSuccess;
 }
@@ -485,7 +480,8 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   Slot tmp;             // only .bk / .buf are read by base_args
   tmp.bk = bk; tmp.buf.p = b.weff;
   eff.w = &tmp; eff.b = nullptr;
-  return conv1x1(e, eff, qkv, 3 * kHidden, l, false, out, out_ld, in, in_ld, at.g->buf.p, b.weff, (long long)at.dim * kHidden,
+  // every consumer of an attention output masks it (Downsample / Upsample input, skip concat, mid blocks)
+  return conv1x1(e, eff, qkv, 3 * kHidden, l, true, out, out_ld, in, in_ld, at.g->buf.p, b.weff, (long long)at.dim * kHidden,
                  at.out_b->buf.p);
 }
 
@@ -552,13 +548,13 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
       double* st2 = next_stats(e);
       CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], b.Q[0], e.Bp, F, T, c, e.s));
       CK(launch_gn_stats(b.S1[0], c, e.Bp, F * T, c, st1, e.s));
-      CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, b.S1[0], c));
+      CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, true, b.S1[0], c));
       CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
-      CK(gn_apply(e, b.S2[0], 0, c, st2, r.g2, r.b2, nullptr, b.Q[0], c, false, b.P[0], c));
+      CK(gn_apply(e, b.S2[0], 0, c, st2, r.g2, r.b2, nullptr, b.Q[0], c, false, true, b.P[0], c));
     } else {
-      CK(resnet(e, d.r1, cur, cur_ld, b.P[l], c));
+      CK(resnet(e, d.r1, cur, cur_ld, b.P[l], c, true));
     }
-    CK(resnet(e, d.r2, b.P[l], c, b.Q[l], c));
+    CK(resnet(e, d.r2, b.P[l], c, b.Q[l], c, false));
     float* hid = l == 0 ? b.P[0] : b.CAT[l] + c;
     int hid_ld = l == 0 ? c : 2 * c;
     CK(attention(e, d.a, b.Q[l], c, hid, hid_ld));
@@ -572,17 +568,17 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
     }
   }
   const int lm = L - 1, cm = h->C[lm];
-  CK(resnet(e, h->mid1, cur, cur_ld, b.P[lm], cm));
+  CK(resnet(e, h->mid1, cur, cur_ld, b.P[lm], cm, false));
   CK(attention(e, h->mid_attn, b.P[lm], cm, b.Q[lm], cm));
   float* xcat = L > 1 ? b.CAT[lm] : b.P[lm];
-  CK(resnet(e, h->mid2, b.Q[lm], cm, xcat, L > 1 ? 2 * cm : cm));
+  CK(resnet(e, h->mid2, b.Q[lm], cm, xcat, L > 1 ? 2 * cm : cm, true));
   const float* fin = xcat;
   int fin_ld = cm;
   for (int u = 0; u < L - 1; ++u) {
     auto& up = h->ups[u];
     const int l = up.r1.level, co = up.r1.cout;
-    CK(resnet(e, up.r1, b.CAT[l], 2 * h->C[l], b.P[l], co));
-    CK(resnet(e, up.r2, b.P[l], co, b.Q[l], co));
+    CK(resnet(e, up.r1, b.CAT[l], 2 * h->C[l], b.P[l], co, true));
+    CK(resnet(e, up.r2, b.P[l], co, b.Q[l], co, false));
     CK(attention(e, up.a, b.Q[l], co, b.P[l], co));
     float* dst = (l - 1 >= 1) ? b.CAT[l - 1] : b.U0;
     int dst_ld = (l - 1 >= 1) ? 2 * h->C[l - 1] : h->C[0];
@@ -594,7 +590,7 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   double* stf = next_stats(e);
   const int c0 = h->C[0];
   CK(conv3x3(e, h->final_conv3, fin, fin_ld, 0, b.S1[0], c0, stf));
-  CK(gn_apply(e, b.S1[0], 0, c0, stf, h->final_g, h->final_b, nullptr, nullptr, 0, false, b.S1[0], c0));
+  CK(gn_apply(e, b.S1[0], 0, c0, stf, h->final_g, h->final_b, nullptr, nullptr, 0, false, false, b.S1[0], c0));
   CK(launch_final_conv(b.S1[0], c0, h->final_w1->buf.p, h->final_b1->buf.p, e.mask, T, e.Bm, out, e.Bp, F, T, c0, e.s));
   return hipSuccess;
 }
@@ -641,6 +637,15 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   hipError_t e = conv_igemm_init();
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   h->build();
+  {
+    int max_cin = 2 * h->C.back();
+    for (int c : h->C) if (2 * c > max_cin) max_cin = 2 * c;
+    size_t zb = ((size_t)max_cin + 64) * sizeof(float);
+    if (hipMalloc(reinterpret_cast<void**>(&h->zeros), zb) != hipSuccess || hipMemset(h->zeros, 0, zb) != hipSuccess) {
+      g_last_error = "hipMalloc failed for the zero page";
+      return US_EHIP;
+    }
+  }
   for (auto& s : h->slots) {
     s->buf.n = numel(s->shape);
     if (hipMalloc(reinterpret_cast<void**>(&s->buf.p), s->buf.n * sizeof(float)) != hipSuccess) {
@@ -656,6 +661,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
   for (auto& s : h->slots) if (s->buf.p) (void)hipFree(s->buf.p);
+  if (h->zeros) (void)hipFree(h->zeros);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;

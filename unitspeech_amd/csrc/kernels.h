@@ -16,14 +16,16 @@ constexpr int kMaxTaps = 16;
 
 // ---- implicit-GEMM convolution on fp32 MFMA -------------------------------------------------------
 struct ConvArgs {
-  const float* in;       // [B][Hin][Win][in_ld], channels [0,Cin)
+  const float* in;       // [B][Hin][Win][in_ld], channels [0,Cin); already multiplied by the frame mask where the
+                         // reference masks this operand
   const float* wt;       // packed [tap][Cin/BK][Cout][BK]
   const float* bias;     // [Cout] or null
-  const float* mask;     // frame mask base [mask_bmod][mask_ld] or null; input column ix reads mask[ix*mask_step]
+  const float* omask;    // optional frame mask applied to the stored value: column ox reads omask[ox*omask_step]
   const float* add;      // optional addend, pixel-indexed like out
-  const float* alpha;    // optional device scalar: out = add + alpha*(acc + bias)
+  const float* alpha;    // optional device scalar: out = (add + alpha*(acc + bias)) * omask
+  const float* zeros;    // zero page (>= max Cin floats) that out-of-image taps read
   float* out;            // [B][Hout][Wout][out_ld]
-  double* stats;         // optional GroupNorm partial sums [B][8][2] (sum, sumsq) of the stored values
+  double* stats;         // optional GroupNorm partial sums [B][8][2] (sum, sumsq) of acc + bias
   long long wt_bstride;  // per-item weight stride in floats (0 = shared weights)
   int in_ld, out_ld, add_ld;
   int B, Hin, Win, Cin, Hout, Wout, Cout;
@@ -31,10 +33,15 @@ struct ConvArgs {
   int oy0, ox0, ostep;   // output pixel = (oy0 + my*ostep, ox0 + mx*ostep)
   int istride;           // input pixel  = (my*istride + dy[tap], mx*istride + dx[tap])
   int ntaps;
-  int mask_ld, mask_step, mask_bmod;
+  int omask_ld, omask_step, omask_bmod;
   int bk;                // 16 or 32: channel chunk the weights were packed for
-  signed char dy[kMaxTaps], dx[kMaxTaps];
-  unsigned char wtap[kMaxTaps];
+  int tm;                // rows per workgroup: 128, 64 or 0 = choose from the grid size
+  unsigned long long dy_bits, dx_bits, wtap_bits;   // 4 bits per tap: dy+8, dx+8, weight tap index
+  void set_tap(int i, int dy, int dx, int wtap) {
+    dy_bits |= (unsigned long long)(dy + 8) << (4 * i);
+    dx_bits |= (unsigned long long)(dx + 8) << (4 * i);
+    wtap_bits |= (unsigned long long)wtap << (4 * i);
+  }
 };
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 hipError_t conv_igemm_init();   // one-time function attributes (dynamic LDS size)
@@ -58,7 +65,8 @@ hipError_t launch_stack_inputs(const float* x, int Bx, const float* mu, int Bmu,
 // ---- GroupNorm(8) + Mish ----------------------------------------------------------------------------
 // stats[B][8][2] += (sum, sumsq) over [n][C] per item; must be zeroed beforehand.
 hipError_t launch_gn_stats(const float* y, int ld, int B, int n, int C, double* stats, hipStream_t s);
-// out = mish(gn(y)) * mask (+ temb[b][c]) (+ res[p][c] * mask)          (Block :46-55, ResnetBlock :69-75)
+// out = mish(gn(y)) * mask (+ temb[b][c]) (+ res[p][c] [* mask]), then * mask again when post_mask
+// (Block :46-55, ResnetBlock :69-75; post_mask pre-applies the `x * mask` of the tensor's consumers)
 struct GnApplyArgs {
   const float* y; int y_ld;
   const double* stats;
@@ -66,6 +74,7 @@ struct GnApplyArgs {
   const float* mask; int mask_ld, mask_step, mask_bmod;   // frame mask, column w reads mask[w*mask_step]
   const float* temb; int temb_ld;                          // optional [B][temb_ld] per-channel addend
   const float* res; int res_ld; int res_masked;            // optional residual (times mask when res_masked)
+  int post_mask;
   float* out; int out_ld;
   int B, H, W, C;
 };

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
       f32x4 rr = *reinterpret_cast<const f32x4*>(rb + p * a.res_ld + c);
       o += a.res_masked ? rr * m : rr;
     }
+    if (a.post_mask) o *= m;
     *reinterpret_cast<f32x4*>(ob + p * a.out_ld + c) = o;
   }
 }
