@@ -1,0 +1,89 @@
+// Micro-benchmark of the implicit-GEMM convolution kernel on synthetic shapes (build: see tools/conv_bench.sh).
+// usage: conv_bench [debug_mask]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../unitspeech_amd/csrc/kernels.h"
+using namespace us;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// Calibration: a pure v_mfma_f32_32x32x2_f32 stream (no memory traffic), `waves` waves per SIMD on every CU; reports the
+// TFLOP/s the device sustains and the shader clock (s_memtime ticks per s_memrealtime 100 MHz tick).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void mfma_peak_kernel(float* out, int iters, unsigned long long* clk) {
+  f32x16 a0, a1, a2, a3;
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }
+  float x = threadIdx.x * 1e-3f, y = blockIdx.x * 1e-3f + 0.5f;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+static void calibrate() {
+  float* out; unsigned long long* clk;
+  CK(hipMalloc(&out, 256 * 8 * 256 * 4)); CK(hipMalloc(&clk, 16));
+  for (int wps : {1, 2, 4}) {
+    int blocks = 256 * wps;   // 256-thread blocks: 4 waves = 1 per SIMD
+    int iters = 20000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, clk);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, clk);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+    double fl = (double)blocks * 4 * iters * 4 * 4096.0;
+    printf("calibration: pure MFMA f32 stream, %d wave(s)/SIMD: %.1f TFLOP/s, shader clock %.3f GHz\n", wps, fl / ms / 1e9,
+           (double)h[0] / (double)h[1] * 0.1);
+  }
+}
+
+struct Shape { const char* name; int B, H, W, Cin, Cout, taps; };
+
+int main(int argc, char** argv) {
+  int debug = argc > 1 ? atoi(argv[1]) : 0;
+  CK(conv_igemm_init());
+  if (debug == 0) calibrate();
+  Shape shapes[] = {{"L0 3x3 128->128", 3, 80, 1024, 128, 128, 9}, {"L1 3x3 256->256", 3, 40, 512, 256, 256, 9},
+                    {"L2 3x3 512->512", 3, 20, 256, 512, 512, 9}, {"L3 3x3 1024->1024", 3, 10, 128, 1024, 1024, 9},
+                    {"L3 3x3 2048->512", 3, 10, 128, 2048, 512, 9}, {"L0 1x1 128->384", 3, 80, 1024, 128, 384, 1},
+                    {"L0 1x1 128->128", 3, 80, 1024, 128, 128, 1}};
+  float* zeros; CK(hipMalloc(&zeros, 16384)); CK(hipMemset(zeros, 0, 16384));
+  for (auto& sh : shapes) {
+    size_t n_in = (size_t)sh.B * sh.H * sh.W * sh.Cin, n_out = (size_t)sh.B * sh.H * sh.W * sh.Cout;
+    size_t n_w = (size_t)sh.taps * sh.Cin * sh.Cout;
+    float *in, *out, *w, *bias;
+    CK(hipMalloc(&in, n_in * 4)); CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&w, n_w * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
+    CK(launch_fill_normal(in, n_in, 1, 1, 0)); CK(launch_fill_normal(w, n_w, 1, 2, 0)); CK(launch_fill_normal(bias, sh.Cout, 1, 3, 0));
+    for (int tm : {128, 64}) {
+      ConvArgs a; memset(&a, 0, sizeof a);
+      a.in = in; a.in_ld = sh.Cin; a.wt = w; a.bias = bias; a.out = out; a.out_ld = sh.Cout; a.zeros = zeros;
+      a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;
+      a.ostep = 1; a.istride = 1; a.ntaps = sh.taps; a.bk = 32; a.tm = tm; a.omask_bmod = 1; a.debug = debug;
+      if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }
+      else a.set_tap(0, 0, 0, 0);
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      for (int i = 0; i < 3; ++i) CK(launch_conv_igemm(a, 0));
+      CK(hipEventRecord(e0, 0));
+      const int reps = 10;
+      for (int i = 0; i < reps; ++i) CK(launch_conv_igemm(a, 0));
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      double fl = 2.0 * sh.B * sh.H * sh.W * (double)sh.Cin * sh.Cout * sh.taps;
+      printf("%-20s tm=%3d debug=%d  %8.1f us  %6.1f TFLOP/s\n", sh.name, tm, debug, ms * 1e3, fl / ms / 1e9);
+    }
+    CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
+  }
+  return 0;
+}

@@ -1,0 +1,8 @@
+#!/bin/bash
+# builds and runs the conv micro-benchmark on the GPU box: tools/conv_bench.sh [debug masks...]
+set -e
+cd "$(dirname "$0")/.."
+# production kernel (debug mask 0) and, with -DUS_CONV_ABLATE, the timing-ablation build for masks != 0
+hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/conv_bench
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -DUS_CONV_ABLATE tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/conv_bench_ablate
+for m in "${@:-0}"; do if [ "$m" = 0 ]; then /tmp/conv_bench 0; else /tmp/conv_bench_ablate $m; fi; done

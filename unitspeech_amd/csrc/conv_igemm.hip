@@ -131,30 +131,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
   __syncthreads();
 
-  for (int step = 0; step < S; ++step) {
-    const bool has_next = step + 1 < S;
-    if (has_next) {
-      if (ch_n == 0) setup_tap(tap_n);
-      dma(ch_n, (step + 1) & 1);
-      if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
-    }
-    const float* base = smem + (step & 1) * BUF;
+  // Fragment reads are double-buffered in registers (set 0 / set 1) and the MFMAs of a step's LAST sub-step are
+  // deferred until after the barrier and after the next step's first fragment reads have been issued, so the LDS
+  // latency behind the barrier is covered by 8*MB MFMAs instead of idling the matrix pipe.
+  constexpr int NS = BK / 8;
+  f32x4 fa0[MB], fb0[2], fa1[MB], fb1[2];
+  auto load_frags = [&](f32x4* fa, f32x4* fb, const float* base, int s_) {
+    const int co = ((2 * s_ + hh) ^ sw) * 4;
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      const int co = ((2 * s + hh) ^ sw) * 4;
-      f32x4 af[MB], bf[2];
+    for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + co);
+    fb[0] = *reinterpret_cast<const f32x4*>(base + b_row + co);
+    fb[1] = *reinterpret_cast<const f32x4*>(base + b_row + 32 * BK + co);
+    // keep the reads AHEAD of the MFMAs that follow in program order (hipcc otherwise sinks them behind the
+    // MFMA block and waits for them at once, exposing the LDS latency)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&](const f32x4* fa, const f32x4* fb) {
 #pragma unroll
-      for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + co);
-      bf[0] = *reinterpret_cast<const f32x4*>(base + b_row + co);
-      bf[1] = *reinterpret_cast<const f32x4*>(base + b_row + 32 * BK + co);
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[0][j], acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[1][j], acc[i][1], 0, 0, 0);
-        }
-    }
+      for (int i = 0; i < MB; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[0][j], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[1][j], acc[i][1], 0, 0, 0);
+      }
+  };
+  auto step_done = [&]() {
     if (++since_flush == kFlushSteps) {
       since_flush = 0;
 #pragma unroll
@@ -166,8 +167,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
     }
-    __syncthreads();   // drains this wave's DMA (vmcnt(0)) and orders every wave's reads before the next overwrite
+  };
+
+  for (int step = 0; step < S; ++step) {
+    const bool has_next = step + 1 < S;
+    if (has_next) {
+      if (ch_n == 0) setup_tap(tap_n);
+#ifdef US_CONV_ABLATE
+      if (!(a.debug & 1))
+#endif
+      dma(ch_n, (step + 1) & 1);
+      if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+    }
+    const float* base = smem + (step & 1) * BUF;
+#ifdef US_CONV_ABLATE      // timing ablations of tools/conv_bench only (results are wrong by construction)
+    if ((a.debug & 2) && step > 0) {
+      mma(fa1, fb1); step_done(); mma(fa0, fb0);
+      if (NS == 4) { mma(fa1, fb1); mma(fa0, fb0); }
+      if (!(a.debug & 4)) __syncthreads();
+      continue;
+    }
+#endif
+    load_frags(fa0, fb0, base, 0);
+    if (step > 0) {           // last sub-step of the previous chunk (fragments were read before the barrier)
+      mma(fa1, fb1);
+      step_done();
+    }
+    load_frags(fa1, fb1, base, 1);
+    mma(fa0, fb0);
+    if (NS == 4) {
+      load_frags(fa0, fb0, base, 2);
+      mma(fa1, fb1);
+      load_frags(fa1, fb1, base, 3);
+      mma(fa0, fb0);
+    }
+#ifdef US_CONV_ABLATE
+    if (!(a.debug & 4))
+#endif
+    __syncthreads();   // drains this wave's DMA and fragment reads (vmcnt(0), lgkmcnt(0)) and orders every wave's
+                       // reads of this buffer before its next overwrite
   }
+  mma(fa1, fb1);
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -256,7 +296,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
   }
   if (g_tm64_threshold < 0) {
     const char* e = getenv("US_TM64_THRESHOLD");
-    g_tm64_threshold = e ? atoi(e) : 512;
+    // measured on MI355X (tools/conv_bench, bench.py): three co-resident 64-row workgroups per CU (136 VGPRs, 48 KB LDS)
+    // hide the per-chunk barrier better than two 128-row ones at every U-Net shape up to a few thousand workgroups
+    g_tm64_threshold = e ? atoi(e) : 8192;
   }
   const int Ms = a.Hs * a.Ws;
   const int nt = (a.Cout + TN - 1) / TN;
