@@ -28,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_inputs, synthetic_state_dict  # noqa: E402
+from unitspeech_amd.sharding import broadcast_state_dict, max_over_ranks  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 HOP, SR = 256, 22050              # conf/hydra_config.py:37,39  -> seconds of speech per mel frame
@@ -45,26 +46,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=1, help="diffusion steps timed on the host CPU")
     return ap.parse_args()
-
-
-def broadcast_weights(cfg, rank, world, device):
-    """Rank 0 generates the synthetic checkpoint; every other rank receives it as ONE packed fp32 blob over RCCL."""
-    import torch.distributed as dist
-    from unitspeech_amd.params import param_shapes
-    shapes = param_shapes(cfg)
-    total = sum(int(np.prod(s)) for s in shapes.values())
-    flat = torch.empty(total, dtype=torch.float32, device=device)
-    if rank == 0:
-        sd = synthetic_state_dict(cfg, 0)
-        flat.copy_(torch.from_numpy(np.concatenate([sd[k].ravel() for k in shapes])))
-    if world > 1:
-        dist.broadcast(flat, src=0)
-    out, off = {}, 0
-    for k, s in shapes.items():
-        n = int(np.prod(s))
-        out[k] = flat[off:off + n].view(*s)
-        off += n
-    return out
 
 
 def cpu_baseline(cfg, frames, n_diff, steps_timed):
@@ -115,7 +96,8 @@ def main():
 
     cfg = DecoderConfig()
     B, T, N = a.batch, a.frames, a.diffusion_steps
-    sd = broadcast_weights(cfg, rank, world, device)
+    # rank 0 generates the synthetic checkpoint; the others receive it as ONE packed 476.6 MB fp32 blob over RCCL
+    sd = broadcast_state_dict(cfg, synthetic_state_dict(cfg, 0) if rank == 0 else None, rank, world, device)
     model = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
     model = model.to(device).eval()
     model.load_state_dict(sd, strict=True)
@@ -146,10 +128,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, world, device)
     assert torch.isfinite(out).all(), "non-finite decoder output"
 
     conv_ms, conv_fl, ev_ms = C.c_double(), C.c_double(), C.c_double()

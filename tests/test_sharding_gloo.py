@@ -1,0 +1,55 @@
+"""The N>1 path on CPU: two gloo ranks, weight broadcast + utterance sharding + max-over-ranks timing reduce."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from unitspeech_amd import DecoderConfig, synthetic_state_dict
+from unitspeech_amd.sharding import broadcast_state_dict, max_over_ranks, shard_range
+
+CFG = DecoderConfig(dim=16)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd0 = synthetic_state_dict(CFG, 0) if rank == 0 else None
+    sd = broadcast_state_dict(CFG, sd0, rank, world, "cpu")
+    checksum = float(sum(v.double().abs().sum() for v in sd.values()))
+    lo, hi = shard_range(11, rank, world)
+    slowest = max_over_ranks(1.0 + rank, world, "cpu")
+    dist.barrier()
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([checksum, lo, hi, slowest]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_and_sharding(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = synthetic_state_dict(CFG, 0)
+    want = float(sum(np.abs(v.astype(np.float64)).sum() for v in ref.values()))
+    r = [np.load(tmp_path / f"r{k}.npy") for k in range(world)]
+    for k in range(world):
+        assert abs(r[k][0] - want) <= 1e-9 * want          # every rank holds rank 0's weights
+        assert r[k][3] == 2.0                               # max over ranks
+    assert (r[0][1], r[0][2], r[1][1], r[1][2]) == (0, 6, 6, 11)
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 64, 512):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
