@@ -97,6 +97,20 @@ int us_fill_normal(float* out, size_t n, uint64_t seed, uint64_t key, us_stream 
 /* FLOPs (2*MAC of conv + attention einsums + MLPs) of one estimator evaluation per item. */
 double us_estimator_flops(us_handle h, int T);
 
+/* ---- training (fine-tune) path: `loss_t` forward + `loss.backward()` through the score network -------------------
+ * us_estimator_forward_train == us_estimator_forward, but every tensor the backward needs is kept inside `workspace`
+ * (sized by us_train_workspace_bytes), which must stay untouched until us_estimator_backward has been enqueued.
+ * us_estimator_backward(grad_out [B, n_feats, T]) writes d loss / d parameter for every `estimator.*` state_dict key
+ * into the caller's buffers (reference layout and shape of that key; overwritten, not accumulated).  keys[i]/grads[i]
+ * pair a key with its device buffer; all estimator keys must be present.  Input gradients are not produced (the
+ * reference never needs them: finetune.py:131-165 optimises decoder parameters only). */
+size_t us_train_workspace_bytes(us_handle h, int B, int T);
+int us_estimator_forward_train(us_handle h, const float* x, const float* mask, const float* mu, const float* t,
+                               const float* spk, float* out, int B, int T, void* workspace, size_t workspace_bytes,
+                               us_stream stream);
+int us_estimator_backward(us_handle h, const float* grad_out, const char* const* keys, float* const* grads, int n_grads,
+                          us_stream stream);
+
 /* Sampled kernel timing for the roofline report.  When enabled, the middle evaluation of every
  * us_reverse_diffusion micro-batch (and every us_estimator_forward) brackets each implicit-GEMM convolution launch,
  * and the evaluation as a whole, with HIP events on the caller's stream.  us_profile_read waits for the recorded

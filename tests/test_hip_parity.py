@@ -183,3 +183,87 @@ def test_errors_are_reported_not_swallowed(tiny):
     z = torch.zeros(1, 80, 12, device=DEV)          # 12 is not a multiple of 8
     with pytest.raises(RuntimeError, match="EINVAL"):
         model(z, torch.ones(1, 1, 12, device=DEV), z, torch.zeros(1, 1, 256, device=DEV), 2, 1.0, 1.0, rng="philox")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training path: loss_t forward + backward through the HIP score network vs the reference's autograd (goldens)
+# ---------------------------------------------------------------------------------------------------------------
+class _ReplayRandn:
+    def __init__(self, draws):
+        self.draws, self.i = list(draws), 0
+
+    def __enter__(self):
+        self.orig = torch.randn
+        torch.randn = self
+        return self
+
+    def __exit__(self, *a):
+        torch.randn = self.orig
+
+    def __call__(self, *shape, **kw):
+        d = self.draws[self.i]
+        self.i += 1
+        return d.to(device=kw.get("device", d.device), dtype=kw.get("dtype", d.dtype))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_loss_and_gradients_vs_reference_autograd(golden, tag):
+    cfg = TINY if tag == "tiny" else FULL
+    g = G(golden(f"loss_{tag}"))
+    model = make_model(cfg).train()
+    with _ReplayRandn([g["z"].to(DEV)]):
+        loss, xt = model.loss_t(g["x0"].to(DEV), g["mask"].to(DEV), g["cond"].to(DEV), g["t"].to(DEV), g["spk_emb"].to(DEV))
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6 * max(1.0, abs(float(g["loss"])))
+    assert l1(xt, g["xt"]) <= 1e-6
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k, ref in g.items():
+        if not k.startswith("grad:"):
+            continue
+        got = params[k[5:]].grad.cpu()
+        scale = ref.abs().max().item() + 1e-12
+        err = (got - ref).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err <= 2e-4, (k, err)
+    sq = 0.0
+    for name, p in params.items():
+        if name in ("text_uncon", "spk_uncon"):
+            assert p.grad is None          # not on the compute_loss path (unitspeech.py:393-411)
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        sq += float((p.grad.double() ** 2).sum())
+    gn = sq ** 0.5
+    print(f"\n[{tag}] loss {loss.item():.6f} (ref {float(g['loss']):.6f})  grad-norm {gn:.6f} (ref {float(g['grad_norm']):.6f})  worst sampled-grad rel err {worst:.2e}")
+    assert abs(gn - float(g["grad_norm"])) <= 1e-4 * float(g["grad_norm"])
+
+
+def test_fine_tune_step_matches_oracle_and_updates_weights(golden):
+    """One `fine_tune` call + Adam step (finetune.py:131-165) on the tiny config: same loss as the reference golden,
+    and a second forward sees the updated weights."""
+    import random
+    g = G(golden("finetune_tiny"))
+    model = make_model(TINY).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-5)
+    random.seed(int(g["py_seed"]))
+    orig_rand = torch.rand
+    torch.rand = lambda *a, **k: g["t_draw"].to(DEV)
+    try:
+        with _ReplayRandn([g["z_draw"].to(DEV)]):
+            loss = model.fine_tune(g["cond_x"].to(DEV), g["y"].to(DEV), g["y_mask"].to(DEV), g["y_lengths"].to(DEV),
+                                   g["y"].shape[-1], g["attn"].to(DEV), g["spk_emb"].to(DEV), int(g["segment_size"]), 80)
+    finally:
+        torch.rand = orig_rand
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
+    before = model.estimator.final_conv.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, model.estimator.final_conv.weight.detach())
+    with torch.no_grad():          # the engine must pick the new weights up
+        x = torch.zeros(1, 80, 16, device=DEV)
+        out = model.estimator(x, torch.ones(1, 1, 16, device=DEV), x, torch.full((1,), 0.5, device=DEV), g["spk_emb"].to(DEV))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = O.estimator_forward(sd, x.cpu(), torch.ones(1, 1, 16), x.cpu(), torch.full((1,), 0.5), g["spk_emb"])
+    assert l1(out, ref) <= 2e-6

@@ -79,7 +79,8 @@ hipError_t launch_attn_ctx_partial(const float* qkv, int B, int n, float* part_c
 // grid (B*heads), 1024 threads = (d, e).  ctx[b][h][d][e] = sum_c w_c[d] part_ctx_c[d][e] / sum_c w_c[d] s_c[d],
 // w_c[d] = exp(m_c[d] - max_c m_c[d]).
 __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __restrict__ part_ctx, const float* __restrict__ part_m,
-                                                                 const float* __restrict__ part_s, int nchunks, float* __restrict__ ctx) {
+                                                                 const float* __restrict__ part_s, int nchunks, float* __restrict__ ctx,
+                                                                 float* __restrict__ colM, float* __restrict__ colS) {
   __shared__ float sM[kDimHead], sS[kDimHead];
   const int b = blockIdx.x / kHeads, h = blockIdx.x % kHeads;
   const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
@@ -93,7 +94,11 @@ __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __
   for (int ch = e; ch < nchunks; ch += 32) S += ps[(long long)ch * kHidden] * expf(pm[(long long)ch * kHidden] - M);
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) S += __shfl_xor(S, off);
-  if (e == 0) { sM[d] = M; sS[d] = S; }
+  if (e == 0) {
+    sM[d] = M;
+    sS[d] = S;
+    if (colM) { colM[(long long)b * kHidden + h * kDimHead + d] = M; colS[(long long)b * kHidden + h * kDimHead + d] = S; }
+  }
   __syncthreads();
   M = sM[d];
   S = sS[d];
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __
 }
 
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
-                                    float* ctx, hipStream_t s) {
-  hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, part_ctx, part_m, part_s, nchunks, ctx);
+                                    float* ctx, float* colM, float* colS, hipStream_t s) {
+  hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, part_ctx, part_m, part_s, nchunks, ctx, colM, colS);
   return hipGetLastError();
 }
 

@@ -34,6 +34,10 @@ struct Slot {
   Kind kind = Kind::RAW;
   int bk = 0;            // packing chunk for conv kinds
   DevBuf buf;            // RAW: reference layout; conv kinds: packed layout
+  DevBuf dg;             // conv kinds (and to_out): repack for the data-gradient GEMM [tap][Cout/bk_dg][Cin][bk_dg]
+  int bk_dg = 0;
+  bool dg_as_1x1 = false;  // RAW [Cout][Cin][1][1] tensor that also needs a dgrad pack (attention to_out)
+  float* grad = nullptr; // caller-owned gradient buffer (reference layout) for the current backward call
   bool loaded = false;
 };
 
@@ -84,6 +88,7 @@ struct us_decoder {
   Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
   int n_resnets = 0;
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
+  std::shared_ptr<void> tape; // saved-activation record of the last us_estimator_forward_train call
   std::string err;
 
   // ---- sampled kernel timing (bench.py roofline leg) ----
@@ -130,6 +135,7 @@ struct us_decoder {
       c.w = add(p + ".weight", {cin, cout, k, k}, Kind::CONVT_IOHW, pick_bk(cin));
     else
       c.w = add(p + ".weight", {cout, cin, k, k}, Kind::CONV_OIHW, pick_bk(cin));
+    c.w->bk_dg = pick_bk(cout);
     c.b = bias ? add(p + ".bias", {cout}) : nullptr;
     return c;
   }
@@ -173,6 +179,8 @@ struct us_decoder {
     a.g = add(p + ".fn.g", {1});
     a.qkv = add_conv(p + ".fn.fn.to_qkv", 3 * kHidden, dim, 1, false);
     a.out_w = add(p + ".fn.fn.to_out.weight", {dim, kHidden, 1, 1});
+    a.out_w->dg_as_1x1 = true;
+    a.out_w->bk_dg = pick_bk(dim);
     a.out_b = add(p + ".fn.fn.to_out.bias", {dim});
     return a;
   }
@@ -472,7 +480,7 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   float* qkv = b.QKV[l];
   CK(conv1x1(e, at.qkv, in, in_ld, l, false, qkv, 3 * kHidden, nullptr, 0, nullptr, nullptr, 0, nullptr));
   CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
-  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, e.s));
+  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, nullptr, nullptr, e.s));
   const int bk = pick_bk(kHidden);
   CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s));
   ConvW eff;
@@ -595,6 +603,8 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   return hipSuccess;
 }
 
+#include "train_host.inc"
+
 int check_ready(us_decoder* h) {
   for (auto& s : h->slots)
     if (!s->loaded) return h->fail(US_EWEIGHTS, "weight '%s' has not been loaded", s->key.c_str());
@@ -648,9 +658,14 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   }
   for (auto& s : h->slots) {
     s->buf.n = numel(s->shape);
-    if (hipMalloc(reinterpret_cast<void**>(&s->buf.p), s->buf.n * sizeof(float)) != hipSuccess) {
+    bool ok = hipMalloc(reinterpret_cast<void**>(&s->buf.p), s->buf.n * sizeof(float)) == hipSuccess;
+    if (ok && (s->kind != Kind::RAW || s->dg_as_1x1)) {
+      s->dg.n = s->buf.n;
+      ok = hipMalloc(reinterpret_cast<void**>(&s->dg.p), s->dg.n * sizeof(float)) == hipSuccess;
+    }
+    if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) if (t->buf.p) (void)hipFree(t->buf.p);
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); }
       return US_EHIP;
     }
   }
@@ -660,7 +675,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) if (s->buf.p) (void)hipFree(s->buf.p);
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
@@ -692,12 +707,16 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
   switch (s->kind) {
     case Kind::RAW:
       US_HIP(h, hipMemcpyAsync(s->buf.p, data, s->buf.n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (s->dg_as_1x1)
+        US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk_dg, st));
       break;
     case Kind::CONV_OIHW:
       US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
+      US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
       break;
     case Kind::CONVT_IOHW:
       US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));
+      US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk_dg, st));
       break;
   }
   s->loaded = true;
@@ -921,6 +940,8 @@ int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* c
   if (reset) { h->prof_conv_ms = h->prof_conv_flops = h->prof_eval_ms = 0; h->prof_conv_launches = h->prof_evals = 0; }
   return US_OK;
 }
+
+#include "train_abi.inc"
 
 const char* us_last_error(us_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 

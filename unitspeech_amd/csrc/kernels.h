@@ -91,8 +91,9 @@ hipError_t launch_final_conv(const float* h, int ld, const float* w, const float
 // Stage 3: fold ctx into to_out: weff[B] packed [1][128/bk][C][bk], weff[c][h*32+d] = sum_e Wout[c][h*32+e]*ctx[h][d][e].
 hipError_t launch_attn_ctx_partial(const float* qkv, int B, int n, float* part_ctx, float* part_m, float* part_s, int nchunks,
                                    hipStream_t s);
+// colM / colS (optional, [B][128]): the softmax column max and sum-exp, kept for the backward pass
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
-                                    float* ctx, hipStream_t s);
+                                    float* ctx, float* colM, float* colS, hipStream_t s);
 hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s);
 inline int attn_nchunks(int n) { return (n + 127) / 128; }
 
@@ -123,5 +124,58 @@ struct SamplerArgs {
 hipError_t launch_sampler_update(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, hipStream_t s);
 hipError_t launch_fill_normal(float* out, size_t n, unsigned long long seed, unsigned long long key, hipStream_t s);
+
+// ---- backward pass (train.hip) ---------------------------------------------------------------------------
+// gw[tap][Cout][Cin] (+ item*gw_bstride) += sum over output pixels of gy[opix][co] * x[ipix(tap)][ci]; same sub-grid /
+// tap geometry fields as ConvArgs.  gw must be zeroed by the caller (fp32 atomics).
+struct WgradArgs {
+  const float* gy; int gy_ld;
+  const float* x; int x_ld;
+  float* gw; long long gw_bstride;
+  int B, Hin, Win, Cin, Hout, Wout, Cout;
+  int Hs, Ws, oy0, ox0, ostep, istride, ntaps;
+  int chunk;             // output pixels per workgroup (multiple of 8)
+  unsigned long long dy_bits, dx_bits, wtap_bits;
+  void set_tap(int i, int dy, int dx, int wtap) {
+    dy_bits |= (unsigned long long)(dy + 8) << (4 * i);
+    dx_bits |= (unsigned long long)(dx + 8) << (4 * i);
+    wtap_bits |= (unsigned long long)wtap << (4 * i);
+  }
+};
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s);
+hipError_t launch_pack_dgrad_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk, hipStream_t s);
+hipError_t launch_colsum(const float* g, int ld, long long rows, int C, const float* scale, float* out, hipStream_t s);
+hipError_t launch_rowsum_per_item(const float* g, int ld, int B, long long n, int C, float* out, hipStream_t s);
+
+// GroupNorm(8)+Mish backward (two passes inside one launcher).  g = gradient w.r.t. the masked activation.
+struct GnBwdArgs {
+  const float* y; int y_ld;          // saved conv output (pre-norm)
+  const double* stats;               // forward (sum, sumsq) [B][8][2]
+  const float* gamma; const float* beta;
+  const float* g; int g_ld;
+  const float* mask; int mask_ld, mask_step, mask_bmod;
+  float* gy; int gy_ld;              // gradient w.r.t. y
+  float* ggamma; float* gbeta;       // [C], accumulated (zeroed by the caller)
+  float* gbias;                      // optional [C]: column sums of gy (bias gradient of the producing conv)
+  double* gsum;                      // scratch [B][8][2], zeroed by the caller
+  int B, H, W, C;
+};
+hipError_t launch_gn_bwd(const GnBwdArgs& a, hipStream_t s);
+
+hipError_t launch_attn_bwd_gctx(const float* qkv, const float* gO, int B, int n, float* gctx, hipStream_t s);
+hipError_t launch_attn_bwd_kv(const float* qkv, const float* ctx, const float* gctx, const float* colM, const float* colS, int B,
+                              int n, float* gqkv, hipStream_t s);
+hipError_t launch_attn_bwd_wout(const float* M1, const float* ctx, const float* wout, const float* g, int B, int C, float* gwout,
+                                float* gg, hipStream_t s);
+hipError_t launch_attn_bwd_bias(const float* colsumG, const float* bout, const float* g, int C, float* gbout, float* gg, hipStream_t s);
+hipError_t launch_attn_weff_dgrad(const float* ctx, const float* wout, float* dst, int B, int C, int bk, hipStream_t s);
+hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float* w, const float* mask, int mask_ld, int mask_bmod,
+                            float* gh, float* gw, float* gb0, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_first_conv_wgrad(const float* in2, const float* gy, const float* gr, int Bp, int F, int T, int C, float* gw3,
+                                   float* gw1, hipStream_t s);
+hipError_t launch_add2(const float* a, int a_ld, const float* b, int b_ld, float* out, int out_ld, long long rows, int C, hipStream_t s);
+hipError_t launch_linear_bwd(const float* gy, int gy_ld, const float* W, const float* x, int x_ld, int rows, int in_dim, int out_dim,
+                             bool mish_in, float* gW, float* gb, float* gx, int gx_ld, bool accumulate_gx, hipStream_t s);
 
 }  // namespace us

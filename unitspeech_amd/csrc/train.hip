@@ -1,0 +1,639 @@
+// Backward-pass kernels of the score network (fine-tune / training step: `loss.backward()` through
+// `GradLogPEstimator2d`, reference finetune.py:163, unitspeech/unitspeech.py:393-405).
+//
+// Data gradients of every convolution reuse the forward implicit-GEMM kernel (conv_igemm.hip) on weights repacked
+// with the channel roles swapped; this file holds what has no forward counterpart: the weight-gradient GEMM
+// (reduction over pixels, both operands pixel-major so MFMA fragments are plain coalesced row loads), GroupNorm+Mish
+// backward, the linear-attention backward pieces, column sums (bias gradients) and the small dense layers.
+#include "kernels.h"
+
+namespace us {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// d/dz [ z * tanh(softplus(z)) ]  (softplus threshold 20 as in the forward)
+__device__ __forceinline__ float mish_grad(float z) {
+  if (z > 20.f) return 1.f;
+  float w = expf(z);
+  float u = w * (w + 2.f);
+  float th = u / (u + 2.f);                 // tanh(softplus(z))
+  float sg = w / (1.f + w);                 // sigmoid(z) = d softplus / dz
+  return th + z * (1.f - th * th) * sg;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight gradient: gw[tap][co][ci] += sum_p gy[outpix(p)][co] * x[inpix(p, tap)][ci]
+// grid (pixel chunks over all items, co-tiles * ci-tiles (64x64), taps); 4 waves split the chunk's pixels,
+// are summed through LDS and leave with one fp32 atomic per element.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  __shared__ float red[64 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = lane & 31, hh = lane >> 5;
+  const int Ms = a.Hs * a.Ws;
+  const int chunks_per_item = (Ms + a.chunk - 1) / a.chunk;
+  const int b = blockIdx.x / chunks_per_item;
+  const int m_lo = (blockIdx.x % chunks_per_item) * a.chunk;
+  const int nci = (a.Cin + 63) / 64;
+  const int co0 = (blockIdx.y / nci) * 64, ci0 = (blockIdx.y % nci) * 64;
+  const int tap = blockIdx.z;
+  const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
+  const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
+  const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);
+  const float* gy_b = a.gy + (long long)b * a.Hout * a.Wout * a.gy_ld;
+  const float* x_b = a.x + (long long)b * a.Hin * a.Win * a.x_ld;
+  const bool cov0 = co0 + l32 < a.Cout, cov1 = co0 + 32 + l32 < a.Cout;
+  const bool civ0 = ci0 + l32 < a.Cin, civ1 = ci0 + 32 + l32 < a.Cin;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int per_wave = a.chunk / 4;
+  const int m_beg = m_lo + wave * per_wave;
+  int m_end = m_beg + per_wave;
+  if (m_end > Ms) m_end = Ms;
+  for (int m = m_beg + hh; m < m_end + hh; m += 2) {   // both halves run the same trip count; lanes past the end feed zeros
+    const bool pv = m < m_end;
+    const int mc = pv ? m : m_beg;
+    const int yy = mc / a.Ws, xx = mc - yy * a.Ws;
+    const long long opix = (long long)(a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep;
+    const int iy = yy * a.istride + dy, ix = xx * a.istride + dx;
+    const bool iv = pv && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+    const long long ipix = iv ? (long long)iy * a.Win + ix : 0;
+    const float* gp = gy_b + opix * a.gy_ld + co0 + l32;
+    const float* xp = x_b + ipix * a.x_ld + ci0 + l32;
+    float a0 = (pv && cov0) ? gp[0] : 0.f, a1 = (pv && cov1) ? gp[32] : 0.f;
+    float b0 = (iv && civ0) ? xp[0] : 0.f, b1 = (iv && civ1) ? xp[32] : 0.f;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+  // cross-wave sum: element (row = co, col = ci) lives at red[row*64 + col]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, col = j * 32 + l32;
+            if (w == 0) red[row * 64 + col] = acc[i][j][r];
+            else red[row * 64 + col] += acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* gw = a.gw + (long long)b * a.gw_bstride + (long long)wt_i * a.Cout * a.Cin;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    int row = i >> 6, col = i & 63;
+    if (co0 + row < a.Cout && ci0 + col < a.Cin) atomicAdd(&gw[(long long)(co0 + row) * a.Cin + ci0 + col], red[i]);
+  }
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
+  if (a.chunk % 8 != 0 || a.chunk <= 0) return hipErrorInvalidValue;
+  const int Ms = a.Hs * a.Ws;
+  dim3 grid(a.B * ((Ms + a.chunk - 1) / a.chunk), ((a.Cout + 63) / 64) * ((a.Cin + 63) / 64), a.ntaps);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// packed [KH*KW][Cout][Cin] -> reference layout (Conv2d [Cout][Cin][KH][KW] or ConvTranspose2d [Cin][Cout][KH][KW])
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int taps, int oihw) {
+  const long long total = (long long)taps * Cout * Cin;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int t = (int)(i % taps);
+    long long r = i / taps;
+    int c2 = (int)(r % (oihw ? Cin : Cout));
+    int c1 = (int)(r / (oihw ? Cin : Cout));
+    int co = oihw ? c1 : c2, ci = oihw ? c2 : c1;
+    dst[i] = src[((long long)t * Cout + co) * Cin + ci];
+  }
+}
+
+hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s) {
+  long long total = (long long)taps * Cout * Cin;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, taps, oihw ? 1 : 0);
+  return hipGetLastError();
+}
+
+// Repack for the data gradient: the dgrad of a conv is a conv with channel roles swapped.
+//   dst[tap][Cout/bk][Cin][bk] (GEMM-N = Cin, GEMM-K = Cout); src Conv2d OIHW or ConvTranspose2d IOHW
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int KH, int KW,
+                                         int oihw, int bk) {
+  const long long total = (long long)KH * KW * Cout * Cin;
+  const int nchunk = Cout / bk;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int k = (int)(i % bk);
+    long long t = i / bk;
+    int ci = (int)(t % Cin); t /= Cin;
+    int ch = (int)(t % nchunk);
+    int tap = (int)(t / nchunk);
+    int co = ch * bk + k;
+    int ky = tap / KW, kx = tap % KW;
+    long long si = oihw ? (((long long)co * Cin + ci) * KH + ky) * KW + kx
+                        : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
+    dst[i] = src[si];
+  }
+}
+
+hipError_t launch_pack_dgrad_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk,
+                                    hipStream_t s) {
+  if (Cout % bk != 0) return hipErrorInvalidValue;
+  long long total = (long long)KH * KW * Cout * Cin;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, KH, KW, oihw ? 1 : 0, bk);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column sums: out[c] += scale * sum over B*n rows of g[row][c]       (bias gradients)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int ld, long long rows, int C, const float* __restrict__ scale,
+                                                     float* __restrict__ out) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float acc = 0.f;
+  if (c < C)
+    for (long long r = blockIdx.x * 4LL + rl; r < rows; r += (long long)gridDim.x * 4) acc += g[r * ld + c];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&out[c], v * (scale ? *scale : 1.f));
+  }
+}
+
+hipError_t launch_colsum(const float* g, int ld, long long rows, int C, const float* scale, float* out, hipStream_t s) {
+  int bx = (int)((rows + 255) / 256);
+  if (bx < 1) bx = 1;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3(bx, (C + 63) / 64), dim3(256), 0, s, g, ld, rows, C, scale, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm(8)+Mish backward.  Forward: xn=(y-mu)*rstd; z=xn*gamma+beta; a=mish(z); consumer sees a*m.
+//   dz = g*m*mish'(z);  ggamma[c] += dz*xn;  gbeta[c] += dz;  per (item, group): S1 = sum dz*gamma, S2 = sum dz*gamma*xn
+//   gy = rstd*(dz*gamma - S1/N - xn*S2/N);  gbias_conv[c] += gy
+// ---------------------------------------------------------------------------------------------------
+struct GnStat { float mean, rstd; };
+__device__ __forceinline__ GnStat gn_stat(const double* st, double cnt) {
+  double mean = st[0] / cnt;
+  double var = st[1] / cnt - mean * mean;
+  if (var < 0) var = 0;
+  GnStat r;
+  r.mean = (float)mean;
+  r.rstd = (float)(1.0 / sqrt(var + 1e-5));
+  return r;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
+  const int b = blockIdx.y;
+  const int C = a.C, cg = C / kGroups;
+  const long long n = (long long)a.H * a.W;
+  const double cnt = (double)n * cg;
+  __shared__ float s_mean[kGroups], s_rstd[kGroups], s_s1[kGroups], s_s2[kGroups];
+  __shared__ float s_ch[2][1024];          // per-channel partial sums (C <= 1024)
+  __shared__ double s_grp[kGroups][2];
+  if (threadIdx.x < kGroups) {
+    GnStat st = gn_stat(a.stats + ((long long)b * kGroups + threadIdx.x) * 2, cnt);
+    s_mean[threadIdx.x] = st.mean;
+    s_rstd[threadIdx.x] = st.rstd;
+    if (PASS == 2) {
+      const double* gs = a.gsum + ((long long)b * kGroups + threadIdx.x) * 2;
+      s_s1[threadIdx.x] = (float)(gs[0] / cnt);
+      s_s2[threadIdx.x] = (float)(gs[1] / cnt);
+    }
+    s_grp[threadIdx.x][0] = 0.0;
+    s_grp[threadIdx.x][1] = 0.0;
+  }
+  for (int i = threadIdx.x; i < C; i += 256) { s_ch[0][i] = 0.f; s_ch[1][i] = 0.f; }
+  __syncthreads();
+  const float* yb = a.y + (long long)b * n * a.y_ld;
+  const float* gb = a.g + (long long)b * n * a.g_ld;
+  float* ob = PASS == 2 ? a.gy + (long long)b * n * a.gy_ld : nullptr;
+  const float* mb = a.mask + (long long)(b % a.mask_bmod) * a.mask_ld;
+  const long long total = n * C;
+  double g1[kGroups], g2[kGroups];
+#pragma unroll
+  for (int k = 0; k < kGroups; ++k) g1[k] = g2[k] = 0.0;
+  // element order: channel fastest; a thread keeps the same channel when 256 % C == 0 or C % 256 == 0 (always true here)
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const float m = mb[(int)(p % a.W) * a.mask_step];
+    const int gi = c / cg;
+    const float xn = (yb[p * a.y_ld + c] - s_mean[gi]) * s_rstd[gi];
+    const float ga = a.gamma[c];
+    const float z = xn * ga + a.beta[c];
+    const float dz = gb[p * a.g_ld + c] * m * mish_grad(z);
+    if (PASS == 1) {
+      atomicAdd(&s_ch[0][c], dz * xn);
+      atomicAdd(&s_ch[1][c], dz);
+#pragma unroll
+      for (int k = 0; k < kGroups; ++k)
+        if (k == gi) { g1[k] += (double)(dz * ga); g2[k] += (double)(dz * ga * xn); }
+    } else {
+      const float gy = s_rstd[gi] * (dz * ga - s_s1[gi] - xn * s_s2[gi]);
+      ob[p * a.gy_ld + c] = gy;
+      atomicAdd(&s_ch[0][c], gy);
+    }
+  }
+  if (PASS == 1) {
+#pragma unroll
+    for (int k = 0; k < kGroups; ++k) {
+      double v1 = g1[k], v2 = g2[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { v1 += __shfl_xor(v1, off); v2 += __shfl_xor(v2, off); }
+      if ((threadIdx.x & 63) == 0) { atomicAdd(&s_grp[k][0], v1); atomicAdd(&s_grp[k][1], v2); }
+    }
+  }
+  __syncthreads();
+  if (PASS == 1) {
+    for (int i = threadIdx.x; i < C; i += 256) {
+      atomicAdd(&a.ggamma[i], s_ch[0][i]);
+      atomicAdd(&a.gbeta[i], s_ch[1][i]);
+    }
+    if (threadIdx.x < kGroups * 2)
+      atomicAdd(&a.gsum[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], s_grp[threadIdx.x >> 1][threadIdx.x & 1]);
+  } else if (a.gbias) {
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&a.gbias[i], s_ch[0][i]);
+  }
+}
+
+hipError_t launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
+  if (a.C > 1024 || a.C % kGroups != 0) return hipErrorInvalidValue;
+  long long total = (long long)a.H * a.W * a.C;
+  int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(gn_bwd_kernel<1>, dim3(blocks, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_bwd_kernel<2>, dim3(blocks, a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// attention backward pieces (see decoder.hip attention_backward for the algebra)
+// ---------------------------------------------------------------------------------------------------
+// gctx[b][h][d][e] += sum_n q[n][h*32+d] * gO[n][h*32+e]          (q: cols [0,128) of qkv, ld 384; gO: ld 128)
+__global__ __launch_bounds__(256) void attn_bwd_gctx_kernel(const float* __restrict__ qkv, const float* __restrict__ gO, int n,
+                                                            float* __restrict__ gctx) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int c = lane & 31, hh = lane >> 5;
+  const float* qp = qkv + (long long)b * n * (3 * kHidden) + h * kDimHead + c;
+  const float* gp = gO + (long long)b * n * kHidden + h * kDimHead + c;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int r0 = chunk * 128;
+#pragma unroll 8
+  for (int j = 0; j < 64; ++j) {
+    int row = r0 + 2 * j + hh;
+    bool v = row < n;
+    int rc = v ? row : n - 1;
+    float qa = qp[(long long)rc * (3 * kHidden)], gb = gp[(long long)rc * kHidden];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v ? qa : 0.f, v ? gb : 0.f, acc, 0, 0, 0);
+  }
+  float* out = gctx + ((long long)b * kHeads + h) * (kDimHead * kDimHead);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int d = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    atomicAdd(&out[d * kDimHead + c], acc[r]);
+  }
+}
+
+hipError_t launch_attn_bwd_gctx(const float* qkv, const float* gO, int B, int n, float* gctx, hipStream_t s) {
+  hipLaunchKernelGGL(attn_bwd_gctx_kernel, dim3((n + 127) / 128, B), dim3(256), 0, s, qkv, gO, n, gctx);
+  return hipGetLastError();
+}
+
+// Per pixel and head: P = exp(k - M)/S;  t[d] = sum_e v[e]*gctx[d][e];  gk[d] = P[d]*(t[d] - cc[d]);  gv[e] = sum_d P[d]*gctx[d][e]
+// with cc[d] = sum_e ctx[d][e]*gctx[d][e].  Writes gk, gv into columns [128,384) of gqkv (ld 384).
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                          const float* __restrict__ gctx, const float* __restrict__ colM,
+                                                          const float* __restrict__ colS, int n, float* __restrict__ gqkv) {
+  __shared__ float sg[kHeads][kDimHead][kDimHead + 1];    // gctx[h][d][e]
+  __shared__ float sgt[kHeads][kDimHead][kDimHead + 1];   // gctx[h][e][d]^T
+  __shared__ float scc[kHidden];
+  const int b = blockIdx.y;
+  const float* gc = gctx + (long long)b * kHeads * kDimHead * kDimHead;
+  const float* cx = ctx + (long long)b * kHeads * kDimHead * kDimHead;
+  for (int i = threadIdx.x; i < kHeads * kDimHead * kDimHead; i += 256) {
+    int h = i >> 10, d = (i >> 5) & 31, e = i & 31;
+    float v = gc[i];
+    sg[h][d][e] = v;
+    sgt[h][e][d] = v;
+  }
+  if (threadIdx.x < kHidden) {
+    const int h = threadIdx.x >> 5, d = threadIdx.x & 31;
+    float acc = 0.f;
+    for (int e = 0; e < kDimHead; ++e) acc += cx[(h * kDimHead + d) * kDimHead + e] * gc[(h * kDimHead + d) * kDimHead + e];
+    scc[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;     // 8 groups of 32 lanes: 2 pixels x 4 heads per pass
+  const int h = grp & 3;
+  const float M = colM[(long long)b * kHidden + h * kDimHead + l], S = colS[(long long)b * kHidden + h * kDimHead + l];
+  const float cc = scc[h * kDimHead + l];
+  for (long long p = blockIdx.x * 2LL + (grp >> 2); p < n; p += (long long)gridDim.x * 2) {
+    const float* row = qkv + ((long long)b * n + p) * (3 * kHidden);
+    const float kk = row[kHidden + h * kDimHead + l];
+    const float vv = row[2 * kHidden + h * kDimHead + l];
+    const float P = expf(kk - M) / S;
+    float t = 0.f, gv = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < kDimHead; ++j) {
+      float vj = __shfl(vv, j, 32), Pj = __shfl(P, j, 32);
+      t += vj * sg[h][l][j];          // d = l, e = j
+      gv += Pj * sgt[h][l][j];        // e = l, d = j : gctx[j][l]
+    }
+    float* orow = gqkv + ((long long)b * n + p) * (3 * kHidden);
+    orow[kHidden + h * kDimHead + l] = P * (t - cc);
+    orow[2 * kHidden + h * kDimHead + l] = gv;
+  }
+}
+
+hipError_t launch_attn_bwd_kv(const float* qkv, const float* ctx, const float* gctx, const float* colM, const float* colS, int B,
+                              int n, float* gqkv, hipStream_t s) {
+  int bx = (n + 1) / 2;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(bx, B), dim3(256), 0, s, qkv, ctx, gctx, colM, colS, n, gqkv);
+  return hipGetLastError();
+}
+
+// From M1[b] = G^T q  ([C][128], fp32, per item) and ctx:
+//   gWout[c][h*32+e] += g * sum_b sum_d M1[b][c][h*32+d] * ctx[b][h][d][e]
+//   gg += sum_b <weff_nat[b], M1[b]>   with weff_nat[b][c][hd] = sum_e Wout[c][he]*ctx[b][h][d][e]  (recomputed here)
+__global__ __launch_bounds__(256) void attn_bwd_wout_kernel(const float* __restrict__ M1, const float* __restrict__ ctx,
+                                                            const float* __restrict__ wout, const float* __restrict__ g, int B, int C,
+                                                            float* __restrict__ gwout, float* __restrict__ gg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float dot = 0.f;
+  if (i < C * kHidden) {
+    const int c = i / kHidden, he = i % kHidden, h = he / kDimHead, e = he % kDimHead;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float* m1 = M1 + ((long long)b * C + c) * kHidden + h * kDimHead;
+      const float* cx = ctx + ((long long)b * kHeads + h) * kDimHead * kDimHead;
+      float weff = 0.f;                       // weff_nat[b][c][h*32 + e'] with e' := e playing the role of d
+      for (int d = 0; d < kDimHead; ++d) {
+        acc += m1[d] * cx[d * kDimHead + e];
+        weff += wout[(long long)c * kHidden + h * kDimHead + d] * cx[e * kDimHead + d];
+      }
+      dot += weff * m1[e];
+    }
+    atomicAdd(&gwout[i], acc * g[0]);
+  }
+  dot = wsum(dot);
+  if ((threadIdx.x & 63) == 0) atomicAdd(gg, dot);
+}
+
+hipError_t launch_attn_bwd_wout(const float* M1, const float* ctx, const float* wout, const float* g, int B, int C, float* gwout,
+                                float* gg, hipStream_t s) {
+  hipLaunchKernelGGL(attn_bwd_wout_kernel, dim3((C * kHidden + 255) / 256), dim3(256), 0, s, M1, ctx, wout, g, B, C, gwout, gg);
+  return hipGetLastError();
+}
+
+// gg += sum_c bout[c]*colsumG[c];  gbout[c] += g*colsumG[c]
+__global__ void attn_bwd_bias_kernel(const float* __restrict__ colsumG, const float* __restrict__ bout, const float* __restrict__ g, int C,
+                                     float* __restrict__ gbout, float* __restrict__ gg) {
+  float dot = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    dot += bout[c] * colsumG[c];
+    atomicAdd(&gbout[c], g[0] * colsumG[c]);
+  }
+  dot = wsum(dot);
+  if ((threadIdx.x & 63) == 0) atomicAdd(gg, dot);
+}
+
+hipError_t launch_attn_bwd_bias(const float* colsumG, const float* bout, const float* g, int C, float* gbout, float* gg, hipStream_t s) {
+  hipLaunchKernelGGL(attn_bwd_bias_kernel, dim3(1), dim3(256), 0, s, colsumG, bout, g, C, gbout, gg);
+  return hipGetLastError();
+}
+
+// weff for the dgrad GEMM: K = C (output channels of to_out), N = 128:  dst[b][C/bk][128][bk], value weff_nat[b][c][hd]
+__global__ __launch_bounds__(256) void attn_weff_dgrad_kernel(const float* __restrict__ ctx, const float* __restrict__ wout,
+                                                              float* __restrict__ dst, int C, int bk) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * kHidden) return;
+  const int co = i / kHidden, hd = i % kHidden;
+  const int h = hd / kDimHead, d = hd % kDimHead;
+  const float* cx = ctx + ((long long)b * kHeads + h) * (kDimHead * kDimHead) + d * kDimHead;
+  const float* w = wout + (long long)co * kHidden + h * kDimHead;
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < kDimHead; ++e) acc = fmaf(w[e], cx[e], acc);
+  dst[(long long)b * C * kHidden + ((long long)(co / bk) * kHidden + hd) * bk + co % bk] = acc;
+}
+
+hipError_t launch_attn_weff_dgrad(const float* ctx, const float* wout, float* dst, int B, int C, int bk, hipStream_t s) {
+  hipLaunchKernelGGL(attn_weff_dgrad_kernel, dim3((C * kHidden + 255) / 256, B), dim3(256), 0, s, ctx, wout, dst, C, bk);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// final projection backward: out[p] = (b0 + sum_c w[c]*h[p][c]*m)*m
+//   gh[p][c] = go[p]*m*w[c];  gw[c] += sum_p go*m*h[p][c];  gb0 += sum_p go*m
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ go, const float* __restrict__ h, int ld,
+                                                        const float* __restrict__ w, const float* __restrict__ mask, int mask_ld,
+                                                        int mask_bmod, int W, long long n, int C, float* __restrict__ gh,
+                                                        float* __restrict__ gw, float* __restrict__ gb0) {
+  const int b = blockIdx.y;
+  __shared__ float s_w[1024];
+  for (int i = threadIdx.x; i < C; i += 256) s_w[i] = 0.f;
+  __syncthreads();
+  const float* mb = mask + (long long)(b % mask_bmod) * mask_ld;
+  const long long total = n * C;
+  float gbacc = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const float g = go[(long long)b * n + p] * mb[(int)(p % W)];
+    const long long idx = ((long long)b * n + p) * ld + c;
+    atomicAdd(&s_w[c], g * h[idx]);
+    gh[idx] = g * w[c];
+    if (c == 0) gbacc += g;
+  }
+  gbacc = wsum(gbacc);
+  if ((threadIdx.x & 63) == 0 && gbacc != 0.f) atomicAdd(gb0, gbacc);
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&gw[i], s_w[i]);
+}
+
+hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float* w, const float* mask, int mask_ld, int mask_bmod,
+                            float* gh, float* gw, float* gb0, int B, int H, int W, int C, hipStream_t s) {
+  if (C > 1024) return hipErrorInvalidValue;
+  long long n = (long long)H * W;
+  int blocks = (int)((n * C + 256 * 16 - 1) / (256 * 16));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks, B), dim3(256), 0, s, go, h, ld, w, mask, mask_ld, mask_bmod, W, n, C, gh, gw, gb0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// first layer (2 input channels) weight gradients: gw3[co][ci][ky][kx] += sum_p gy[p][co]*in2[p+d][ci];
+// gw1[co][ci] += sum_p gr[p][co]*in2[p][ci]     (reference layouts, written with atomics)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const float* __restrict__ in2, const float* __restrict__ gy,
+                                                               const float* __restrict__ gr, int F, int T, int C,
+                                                               float* __restrict__ gw3, float* __restrict__ gw1) {
+  // one block = one mel row of one item; thread = output channel (looped), registers hold the 18 + 2 partial sums
+  const int b = blockIdx.y, f = blockIdx.x;
+  for (int co = threadIdx.x; co < C; co += 256) {
+    float a3[18], a1[2];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) a3[i] = 0.f;
+    a1[0] = a1[1] = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const long long p = ((long long)b * F + f) * T + t;
+      const float g = gy[p * C + co], r = gr[p * C + co];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int ff = f + ky - 1;
+        if (ff < 0 || ff >= F) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tt = t + kx - 1;
+          if (tt < 0 || tt >= T) continue;
+          const float* ip = in2 + (((long long)b * F + ff) * T + tt) * 2;
+          a3[ky * 3 + kx] += g * ip[0];
+          a3[9 + ky * 3 + kx] += g * ip[1];
+        }
+      }
+      const float* ip = in2 + p * 2;
+      a1[0] += r * ip[0];
+      a1[1] += r * ip[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 18; ++i) atomicAdd(&gw3[co * 18 + i], a3[i]);
+    atomicAdd(&gw1[co * 2], a1[0]);
+    atomicAdd(&gw1[co * 2 + 1], a1[1]);
+  }
+}
+
+hipError_t launch_first_conv_wgrad(const float* in2, const float* gy, const float* gr, int Bp, int F, int T, int C, float* gw3,
+                                   float* gw1, hipStream_t s) {
+  hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(F, Bp), dim3(256), 0, s, in2, gy, gr, F, T, C, gw3, gw1);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small dense layers: y[r][o] = bias[o] + sum_i W[o][i]*f(x[r][i])
+//   gW[o][i] += sum_r gy[r][o]*f(x[r][i]);  gb[o] += sum_r gy[r][o];  gx[r][i] (+)= f'(x[r][i]) * sum_o gy[r][o]*W[o][i]
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mish_fwd(float x) {
+  if (x > 20.f) return x;
+  float w = expf(x);
+  float u = w * (w + 2.f);
+  return x * (u / (u + 2.f));
+}
+
+__global__ void linear_bwd_w_kernel(const float* __restrict__ gy, int gy_ld, const float* __restrict__ x, int x_ld, int rows, int in_dim,
+                                    int out_dim, int mish_in, float* __restrict__ gW, float* __restrict__ gb) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= (long long)out_dim * in_dim) return;
+  const int o = (int)(i / in_dim), k = (int)(i % in_dim);
+  float acc = 0.f, accb = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    float xv = x[(long long)r * x_ld + k];
+    if (mish_in) xv = mish_fwd(xv);
+    const float g = gy[(long long)r * gy_ld + o];
+    acc += g * xv;
+    accb += g;
+  }
+  atomicAdd(&gW[i], acc);
+  if (k == 0 && gb) atomicAdd(&gb[o], accb);
+}
+
+__global__ void linear_bwd_x_kernel(const float* __restrict__ gy, int gy_ld, const float* __restrict__ W, const float* __restrict__ x,
+                                    int x_ld, int rows, int in_dim, int out_dim, int mish_in, int accumulate, float* __restrict__ gx,
+                                    int gx_ld) {
+  const int r = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= in_dim) return;
+  float acc = 0.f;
+  for (int o = 0; o < out_dim; ++o) acc += gy[(long long)r * gy_ld + o] * W[(long long)o * in_dim + k];
+  if (mish_in) acc *= mish_grad(x[(long long)r * x_ld + k]);
+  float* dst = gx + (long long)r * gx_ld + k;
+  *dst = accumulate ? *dst + acc : acc;
+}
+
+hipError_t launch_linear_bwd(const float* gy, int gy_ld, const float* W, const float* x, int x_ld, int rows, int in_dim, int out_dim,
+                             bool mish_in, float* gW, float* gb, float* gx, int gx_ld, bool accumulate_gx, hipStream_t s) {
+  long long tot = (long long)out_dim * in_dim;
+  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gy, gy_ld, x, x_ld, rows, in_dim, out_dim,
+                     mish_in ? 1 : 0, gW, gb);
+  if (gx)
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((in_dim + 255) / 256, rows), dim3(256), 0, s, gy, gy_ld, W, x, x_ld, rows, in_dim, out_dim,
+                       mish_in ? 1 : 0, accumulate_gx ? 1 : 0, gx, gx_ld);
+  return hipGetLastError();
+}
+
+// out[b][c] = sum over the item's n pixels of g[p][c]       (time-embedding gradient of a ResnetBlock)
+__global__ __launch_bounds__(256) void rowsum_per_item_kernel(const float* __restrict__ g, int ld, long long n, int C, float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float acc = 0.f;
+  if (c < C)
+    for (long long r = blockIdx.x * 4LL + rl; r < n; r += (long long)gridDim.x * 4) acc += g[((long long)b * n + r) * ld + c];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(&out[(long long)b * C + c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+hipError_t launch_rowsum_per_item(const float* g, int ld, int B, long long n, int C, float* out, hipStream_t s) {
+  int bx = (int)((n + 255) / 256);
+  if (bx < 1) bx = 1;
+  if (bx > 128) bx = 128;
+  hipLaunchKernelGGL(rowsum_per_item_kernel, dim3(bx, (C + 63) / 64, B), dim3(256), 0, s, g, ld, n, C, out);
+  return hipGetLastError();
+}
+
+// out[r][0:C] = a[r][0:C] + b[r][0:C] with independent row strides (skip-connection gradient merge)
+__global__ void add2_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld, float* __restrict__ out, int out_ld,
+                            long long rows, int C) {
+  const long long total = rows * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C;
+    const int c = (int)(i % C);
+    out[r * out_ld + c] = a[r * a_ld + c] + b[r * b_ld + c];
+  }
+}
+
+hipError_t launch_add2(const float* a, int a_ld, const float* b, int b_ld, float* out, int out_ld, long long rows, int C, hipStream_t s) {
+  long long total = rows * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(add2_kernel, dim3(blocks), dim3(256), 0, s, a, a_ld, b, b_ld, out, out_ld, rows, C);
+  return hipGetLastError();
+}
+
+}  // namespace us

@@ -176,6 +176,42 @@ class _Engine:
         return self.workspace
 
 
+class _EstimatorFn(torch.autograd.Function):
+    """autograd bridge: forward = us_estimator_forward_train (activations stay in the workspace), backward =
+    us_estimator_backward, which returns d loss / d parameter for every estimator tensor."""
+
+    @staticmethod
+    def forward(ctx, est, eng, x, mask, mu, t, spk, keys, *params):
+        B, F, T = x.shape
+        dev = x.device
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            nbytes = eng.lib.us_train_workspace_bytes(eng.handle, B, T)
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            rc = eng.lib.us_estimator_forward_train(eng.handle, _dev_ptr(x), _dev_ptr(mask), _dev_ptr(mu), _dev_ptr(t), _dev_ptr(spk),
+                                                    _dev_ptr(out), B, T, _dev_ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, eng.handle, "us_estimator_forward_train")
+        ctx.eng, ctx.ws, ctx.keys, ctx.dev = eng, ws, keys, dev
+        ctx.inputs = (x, mask, mu, t, spk)      # keep the operands alive until backward has been enqueued
+        ctx.param_meta = [(p.shape, p.dtype) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng, keys, dev = ctx.eng, ctx.keys, ctx.dev
+        g = _f32c(grad_out, dev)
+        grads = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, _ in ctx.param_meta]
+        n = len(keys)
+        ckeys = (C.c_char_p * n)(*[k.encode() for k in keys])
+        cptrs = (C.c_void_p * n)(*[gr.data_ptr() for gr in grads])
+        with torch.cuda.device(dev):
+            rc = eng.lib.us_estimator_backward(eng.handle, _dev_ptr(g), ckeys, cptrs, n, _stream())
+        _lib.check(rc, eng.handle, "us_estimator_backward")
+        ctx.ws = None
+        ctx.inputs = None
+        return (None, None, None, None, None, None, None, None, *[gr.to(dt) for gr, (_, dt) in zip(grads, ctx.param_meta)])
+
+
 class GradLogPEstimator2d(BaseModule):
     """U-Net score network; `unitspeech/unitspeech.py:124-201`."""
 
@@ -234,8 +270,6 @@ class GradLogPEstimator2d(BaseModule):
 
     def forward(self, x, mask, mu, t, spk_emb=None):
         """x, mu: [B, n_feats, T]; mask: [B, 1, T]; t: [B]; spk_emb: [B, 1, spk_emb_dim] -> [B, n_feats, T]."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP decoder's backward pass is not built yet: call under torch.no_grad()")
         if spk_emb is None:
             raise ValueError("spk_emb is required (the reference squeezes it unconditionally, unitspeech.py:168)")
         dev = x.device
@@ -249,6 +283,12 @@ class GradLogPEstimator2d(BaseModule):
             weights += self._owner._own_weights()
         eng.sync_weights(weights, dev)
         x, mu, mask, t, spk = (_f32c(v, dev) for v in (x, mu, mask, t, spk_emb))
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training step (`loss_t` under autograd, unitspeech.py:393-405): parameters only; the reference never
+            # differentiates w.r.t. x / mu / spk_emb on this path
+            named = list(self._named_weights())
+            return _EstimatorFn.apply(self, eng, x.detach(), mask.detach(), mu.detach(), t.detach(), spk.detach(),
+                                      [k for k, _ in named], *[p for _, p in named])
         out = torch.empty_like(x)
         with torch.cuda.device(dev):
             nbytes = eng.lib.us_workspace_bytes(eng.handle, B, T)
