@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Fine-tune step benchmark (BASELINE.json configs[3]: 500-iteration speaker adaptation, B=1, 176-frame crops, Adam 2e-5).
+
+Runs the reference's inner loop of finetune.py:131-165 (decoder.fine_tune -> loss.backward -> clip_grad_norm_(1) ->
+Adam.step) on synthetic data with the HIP decoder and reports seconds per iteration; optionally checks the loss
+trajectory of the first iterations against the CPU oracle driven by torch autograd with the same draws.
+    python bench_finetune.py [--iters 50] [--check 3]
+"""
+import argparse
+import json
+import random
+import time
+
+import numpy as np
+import torch
+
+from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_state_dict
+from unitspeech_amd.util import generate_path, sequence_mask
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=600, help="length of the reference utterance's mel")
+    ap.add_argument("--segment", type=int, default=176, help="out_size: fix_len_compatibility(2*22050//256)")
+    ap.add_argument("--check", type=int, default=0, help="compare the first K losses with the CPU oracle (slow)")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cfg = DecoderConfig()
+    sd_np = synthetic_state_dict(cfg, 0)
+    model = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model = model.to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-5)
+
+    g = np.random.Generator(np.random.Philox(key=2024))
+    L, Lu = a.frames, a.frames // 3
+    y = torch.from_numpy(g.standard_normal((1, cfg.n_feats, L), dtype=np.float32)).clamp(-1, 1)
+    cond_x = torch.from_numpy(g.standard_normal((1, cfg.n_feats, Lu), dtype=np.float32) * 0.5)
+    dur = torch.full((1, Lu), 3.0)
+    y_lengths = torch.LongTensor([L])
+    y_mask = sequence_mask(y_lengths, L).unsqueeze(1).float()
+    attn = generate_path(dur, (torch.ones(1, 1, Lu).unsqueeze(-1) * y_mask.unsqueeze(2)).squeeze(1))
+    spk = torch.from_numpy(g.standard_normal((1, 1, cfg.spk_emb_dim), dtype=np.float32))
+    spk = spk / spk.norm()
+    dv = lambda t: t.to(dev)
+    cond_x_d, y_d, y_mask_d, y_len_d, attn_d, spk_d = map(dv, (cond_x, y, y_mask, y_lengths, attn, spk))
+
+    def step():
+        loss = model.fine_tune(cond_x_d, y_d, y_mask_d, y_len_d, L, attn_d, spk_d, a.segment, cfg.n_feats)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
+        opt.step()
+        return loss
+
+    random.seed(0); torch.manual_seed(0)
+    losses = []
+    for _ in range(a.warmup):
+        losses.append(step().item())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
+    res = {"metric": "fine-tune seconds/iteration (B=1, 176-frame crop, fwd+bwd+clip+Adam)", "value": dt, "unit": "s/iter",
+           "iters": a.iters, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": loss.item()}
+
+    if a.check > 0:
+        # same python/torch draws replayed on the CPU oracle (fresh weights, same optimiser)
+        from oracle import decoder_oracle as O
+        sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+        opt2 = torch.optim.Adam(list(sd.values()), lr=2e-5)
+        random.seed(0); torch.manual_seed(0)
+        ref_losses = []
+        for _ in range(min(a.check, a.warmup)):
+            y_cut, m_cut, cond_y = O.fine_tune_segment(cond_x, y, y_mask, y_lengths, L, attn, a.segment, cfg.n_feats)
+            t = torch.clamp(torch.rand(1, device=dev).cpu(), 1e-5, 1 - 1e-5)          # same device generator stream as the HIP run
+            z = torch.randn(y_cut.shape, device=dev).cpu()
+            lossr, _ = O.loss_t(sd, y_cut, m_cut, cond_y, t, spk, z, cfg.n_feats)
+            opt2.zero_grad()
+            lossr.backward()
+            torch.nn.utils.clip_grad_norm_(list(sd.values()), 1)
+            opt2.step()
+            ref_losses.append(lossr.item())
+        res["oracle_losses"] = ref_losses
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
