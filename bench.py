@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=50)
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=1, help="diffusion steps timed on the host CPU")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="diffusion steps timed on the host CPU")
     return ap.parse_args()
 
 

@@ -5,4 +5,11 @@ cd "$(dirname "$0")/.."
 # production kernel (debug mask 0) and, with -DUS_CONV_ABLATE, the timing-ablation build for masks != 0
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/conv_bench
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -DUS_CONV_ABLATE tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/conv_bench_ablate
+for pm in 1 2; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DUS_PRIO_MODE=$pm tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/conv_bench_prio$pm
+done
+if [ "$1" = prio ]; then
+  for r in 1 2; do for pm in 0 1 2; do echo "== PRIO_MODE $pm (round $r)"; if [ $pm = 0 ]; then /tmp/conv_bench 9 | grep "tm= 64"; else /tmp/conv_bench_prio$pm 9 | grep "tm= 64"; fi; done; done
+  exit 0
+fi
 for m in "${@:-0}"; do if [ "$m" = 0 ]; then /tmp/conv_bench 0; else /tmp/conv_bench_ablate $m; fi; done

@@ -125,6 +125,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int a_row = (wm * WM + l32) * BK;
   const int b_row = TM * BK + (wn * 64 + l32) * BK;
 
+#ifndef US_PRIO_MODE
+#define US_PRIO_MODE 0
+#endif
+#if US_PRIO_MODE == 1
+  // static per-workgroup priority: co-resident workgroups that would otherwise march in lockstep (same code, same
+  // barrier cadence, one shared matrix pipe per SIMD) take turns instead
+  {
+    const unsigned hsh = (blockIdx.x * 2654435761u + blockIdx.y * 40503u + blockIdx.z * 7u) >> 13;
+    if ((hsh & 3) == 1) __builtin_amdgcn_s_setprio(1);
+    else if ((hsh & 3) == 2) __builtin_amdgcn_s_setprio(2);
+    else if ((hsh & 3) == 3) __builtin_amdgcn_s_setprio(3);
+  }
+#endif
   int tap_n = 0, ch_n = 0;
   setup_tap(0);
   dma(0, 0);
@@ -147,6 +160,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
   auto mma = [&](const f32x4* fa, const f32x4* fb) {
+#if US_PRIO_MODE == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -154,6 +170,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[0][j], acc[i][0], 0, 0, 0);
         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[1][j], acc[i][1], 0, 0, 0);
       }
+#if US_PRIO_MODE == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   auto step_done = [&]() {
     if (++since_flush == kFlushSteps) {
@@ -297,8 +316,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
   if (g_tm64_threshold < 0) {
     const char* e = getenv("US_TM64_THRESHOLD");
     // measured on MI355X (tools/conv_bench, bench.py): three co-resident 64-row workgroups per CU (136 VGPRs, 48 KB LDS)
-    // hide the per-chunk barrier better than two 128-row ones at every U-Net shape up to a few thousand workgroups
-    g_tm64_threshold = e ? atoi(e) : 8192;
+    // hide the per-chunk barrier better than two 128-row ones at every U-Net shape and batch measured (B'=3 and 24)
+    g_tm64_threshold = e ? atoi(e) : (1 << 30);
   }
   const int Ms = a.Hs * a.Ws;
   const int nt = (a.Cout + TN - 1) / TN;
