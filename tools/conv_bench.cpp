@@ -30,9 +30,82 @@ __global__ void mfma_peak_kernel(float* out, int iters, unsigned long long* clk)
   if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
+// Structural calibration: the conv kernel's inner-loop skeleton (TM=64 variant: 2 accumulators, 32 MFMAs per step) with
+// its ingredients switched on one at a time.  FLAGS: 1 = barrier per step, 2 = 12 ds_read_b128 per step, 4 = 6 LDS-DMA
+// pieces per step (double-buffered like the real kernel).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int FLAGS, int PIECES = 6, int BUF = 0>
+__global__ __launch_bounds__(256, 2) void skeleton_kernel(const float* __restrict__ g, float* out, int steps) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  f32x16 a0, a1;
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+  f32x4v fa = {1.f, 2.f, 3.f, 4.f}, fb0 = {1.f, 1.f, 2.f, 2.f}, fb1 = {3.f, 1.f, 2.f, 1.f};
+  const float* src = g + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (int s = 0; s < steps; ++s) {
+    float* buf = lds + ((s + 1) & 1) * 6144;
+    if (FLAGS & 4) {
+      if (BUF) {
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7fffffff, 0x00020000);
+        const int voff = (blockIdx.x * 256 + threadIdx.x) * 16;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(buf + (wave * 6 + j) * 256), 16, voff,
+                                                   ((s * PIECES + j) & 63) * 262144, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)((s * PIECES + j) & 63) * 65536),
+                                           (__attribute__((address_space(3))) void*)(buf + (wave * 6 + j) * 256), 16, 0, 0);
+      }
+    }
+    const float* rd = lds + (s & 1) * 6144 + lane * 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (FLAGS & 2) {
+        fa = *reinterpret_cast<const f32x4v*>(rd + sub * 256);
+        fb0 = *reinterpret_cast<const f32x4v*>(rd + 1024 + sub * 256);
+        fb1 = *reinterpret_cast<const f32x4v*>(rd + 2048 + sub * 256);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb0[j], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb1[j], a1, 0, 0, 0);
+      }
+    }
+    if (FLAGS & 1) __syncthreads();
+  }
+  float sum = 0.f;
+  for (int r = 0; r < 16; ++r) sum += a0[r] + a1[r];
+  out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
+template <int FLAGS, int PIECES = 6, int BUF = 0>
+static void run_skeleton(const float* g, float* out) {
+  const int steps = 288, blocks = 256 * 3 * 2;     // 3 resident workgroups per CU, 2 rounds
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skeleton_kernel<FLAGS, PIECES, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((skeleton_kernel<FLAGS, PIECES, BUF>), dim3(blocks), dim3(256), 49152, 0, g, out, steps);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((skeleton_kernel<FLAGS, PIECES, BUF>), dim3(blocks), dim3(256), 49152, 0, g, out, steps);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+  double fl = (double)blocks * 4 * steps * 32 * 4096.0;
+  printf("skeleton flags=%d (1=barrier 2=ds_read 4=lds-dma) pieces/step=%d %s: %7.1f us  %6.1f TFLOP/s\n", FLAGS, PIECES,
+         BUF ? "buffer_load..lds" : "global_load_lds", ms * 1e3, fl / ms / 1e9);
+}
+
 static void calibrate() {
   float* out; unsigned long long* clk;
   CK(hipMalloc(&out, 256 * 8 * 256 * 4)); CK(hipMalloc(&clk, 16));
+  {
+    float* g; CK(hipMalloc(&g, (size_t)64 * 65536 * 4 + 1536 * 256 * 16)); CK(hipMemset(g, 0, (size_t)64 * 65536 * 4 + 1536 * 256 * 16));
+    run_skeleton<0>(g, out); run_skeleton<1>(g, out); run_skeleton<2>(g, out); run_skeleton<3>(g, out);
+    run_skeleton<7>(g, out); run_skeleton<7, 4>(g, out); run_skeleton<7, 3>(g, out); run_skeleton<7, 2>(g, out);
+    run_skeleton<7, 6, 1>(g, out); run_skeleton<7, 4, 1>(g, out); run_skeleton<7, 3, 1>(g, out); run_skeleton<7, 2, 1>(g, out);
+    CK(hipFree(g));
+  }
   for (int wps : {1, 2, 4}) {
     int blocks = 256 * wps;   // 256-thread blocks: 4 waves = 1 per SIMD
     int iters = 20000;

@@ -30,9 +30,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TN = 128;
 
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst_wave_uniform) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+// One wave-wide LDS-DMA piece: 64 lanes x 16 bytes, lane l lands at lds_dst + 16*l.  `buffer_load_dwordx4 ... offen lds`
+// (SGPR descriptor + 32-bit per-lane byte offset + scalar offset) instead of `global_load_lds_dwordx4` (64-bit per-lane
+// address): measured on MI355X in the kernel's own skeleton (tools/conv_bench), 6 pieces per 32 MFMAs cost 15 % of the
+// MFMA rate as global_load_lds and nothing as buffer loads.  A lane whose offset is >= num_records reads zeros
+// (raw-buffer range check), which implements the zero padding of out-of-image taps.
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff_bytes, unsigned soff_bytes, float* lds_dst_wave_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, (int)voff_bytes,
+                                           (int)soff_bytes, 0, 0);
 }
 
 template <int BK, int WM>
@@ -71,19 +76,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     mx[j] = mc - my[j] * a.Ws;
     achunk[j] = (lpos ^ ((r / SWZ_DIV) % CPR)) * 4;   // source chunk (floats) for this LDS slot
   }
-  long long boff[IB];   // float offset of this lane's B source inside a [Cout][BK] slab
+  unsigned boff[IB];    // byte offset of this lane's B source inside a [Cout][BK] slab
 #pragma unroll
   for (int j = 0; j < IB; ++j) {
     const int r = (wave * IB + j) * RPI + lrow;
     int n = n0 + r;
     n = n < a.Cout ? n : a.Cout - 1;                  // clamp: columns >= Cout are never stored
-    boff[j] = (long long)n * BK + (lpos ^ ((r / SWZ_DIV) % CPR)) * 4;
+    boff[j] = (unsigned)(n * BK + (lpos ^ ((r / SWZ_DIV) % CPR)) * 4) * 4u;
   }
-  const float* wt_b = a.wt + (long long)b * a.wt_bstride;
-  const float* in_b = a.in + (long long)b * a.Hin * a.Win * a.in_ld;
+  // buffer descriptors: A = this item's activation tensor (range-checked), B = this item's packed weights
+  const unsigned a_bytes = (unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.in_ld * 4u;     // < 2^31 (host-checked)
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (long long)b * a.Hin * a.Win * a.in_ld), 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)b * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
 
-  const float* aptr[IA];
-  const float* wtap = nullptr;
+  unsigned aoff[IA];    // per-lane byte offset of the current tap's source row chunk (>= a_bytes: reads zeros)
+  unsigned wtap_bytes = 0;
   auto setup_tap = [&](int tap) {
     const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
     const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
@@ -92,19 +101,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     for (int j = 0; j < IA; ++j) {
       const int iy = my[j] * a.istride + dy, ix = mx[j] * a.istride + dx;
       const bool ok = mv[j] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-      const float* p = in_b + ((long long)iy * a.Win + ix) * a.in_ld;
-      aptr[j] = (ok ? p : a.zeros) + achunk[j];       // zero page is >= Cin floats long
+      const unsigned off = ((unsigned)(iy * a.Win + ix) * (unsigned)a.in_ld + (unsigned)achunk[j]) * 4u;
+      aoff[j] = ok ? off : a_bytes;
     }
-    wtap = wt_b + (long long)wt_i * nchunk * a.Cout * BK;
+    wtap_bytes = (unsigned)wt_i * (unsigned)nchunk * (unsigned)a.Cout * (unsigned)(BK * 4);
   };
   auto dma = [&](int ch, int buf) {
     float* As = smem + buf * BUF;
     float* Bs = As + TM * BK;
+    const unsigned ach = (unsigned)ch * (unsigned)(BK * 4);
 #pragma unroll
-    for (int j = 0; j < IA; ++j) glds16(aptr[j] + ch * BK, As + (wave * IA + j) * RPI * BK);
-    const float* wb = wtap + (long long)ch * a.Cout * BK;
+    for (int j = 0; j < IA; ++j) blds16(rsrc_a, aoff[j], ach, As + (wave * IA + j) * RPI * BK);
+    const unsigned wb = wtap_bytes + (unsigned)ch * (unsigned)a.Cout * (unsigned)(BK * 4);
 #pragma unroll
-    for (int j = 0; j < IB; ++j) glds16(wb + boff[j], Bs + (wave * IB + j) * RPI * BK);
+    for (int j = 0; j < IB; ++j) blds16(rsrc_b, boff[j], wb, Bs + (wave * IB + j) * RPI * BK);
   };
 
   // Two-level accumulation: the MFMA chain (an exact fp32 fma chain) runs over 128 K-elements, then is folded into
@@ -308,7 +318,10 @@ static int g_tm64_threshold = -1;
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
   if ((a.bk != 16 && a.bk != 32) || a.Cin % a.bk != 0 || a.ntaps < 1 || a.ntaps > kMaxTaps) return hipErrorInvalidValue;
-  if (a.in_ld % 4 != 0 || !a.zeros) return hipErrorInvalidValue;   // 16-byte DMA pieces of the activation rows
+  if (a.in_ld % 4 != 0) return hipErrorInvalidValue;   // 16-byte DMA pieces of the activation rows
+  // 32-bit buffer offsets: one item's activation tensor and the packed weights must stay below 2 GiB
+  if ((long long)a.Hin * a.Win * a.in_ld * 4 >= (1LL << 31) || (long long)kMaxTaps * a.Cout * a.Cin * 4 >= (1LL << 31))
+    return hipErrorInvalidValue;
   if (a.stats) {
     int cg = a.Cout / kGroups;
     if (a.Cout % kGroups != 0 || (cg & (cg - 1)) != 0) return hipErrorInvalidValue;
