@@ -76,12 +76,12 @@ hipError_t launch_attn_ctx_partial(const float* qkv, int B, int n, float* part_c
   return hipGetLastError();
 }
 
-// grid (B*heads), 1024 threads = (d, e).  ctx[b][h][d][e] = sum_c w_c[d] part_ctx_c[d][e] / sum_c w_c[d] s_c[d],
-// w_c[d] = exp(m_c[d] - max_c m_c[d]).
-__global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __restrict__ part_ctx, const float* __restrict__ part_m,
-                                                                 const float* __restrict__ part_s, int nchunks, float* __restrict__ ctx,
-                                                                 float* __restrict__ colM, float* __restrict__ colS) {
-  __shared__ float sM[kDimHead], sS[kDimHead];
+// Merge of the chunk partials, two launches:
+//   stats : grid (B*heads), 1024 threads: column max M[d] and S[d] = sum_c s_c[d] exp(m_c[d] - M[d])
+//   accum : grid (B*heads, nsplit), 1024 threads = (d, e): ctx[d][e] += sum_{c in split} exp(m_c[d]-M[d]) part_c[d][e] / S[d]
+// (ctx zeroed by the launcher; splitting the chunk range keeps the level-0 merge, 640 chunks per item, off the critical path)
+__global__ __launch_bounds__(1024) void attn_ctx_stats_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s,
+                                                              int nchunks, float* __restrict__ colM, float* __restrict__ colS) {
   const int b = blockIdx.x / kHeads, h = blockIdx.x % kHeads;
   const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
   const float* pm = part_m + (long long)b * nchunks * kHidden + h * kDimHead + d;
@@ -95,25 +95,54 @@ __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) S += __shfl_xor(S, off);
   if (e == 0) {
-    sM[d] = M;
-    sS[d] = S;
-    if (colM) { colM[(long long)b * kHidden + h * kDimHead + d] = M; colS[(long long)b * kHidden + h * kDimHead + d] = S; }
+    colM[(long long)b * kHidden + h * kDimHead + d] = M;
+    colS[(long long)b * kHidden + h * kDimHead + d] = S;
   }
-  __syncthreads();
-  M = sM[d];
-  S = sS[d];
+}
+
+__global__ __launch_bounds__(1024) void attn_ctx_accum_kernel(const float* __restrict__ part_ctx, const float* __restrict__ part_m,
+                                                              const float* __restrict__ colM, const float* __restrict__ colS, int nchunks,
+                                                              int per_split, float* __restrict__ ctx) {
+  const int b = blockIdx.x / kHeads, h = blockIdx.x % kHeads;
+  const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
+  const float M = colM[(long long)b * kHidden + h * kDimHead + d], S = colS[(long long)b * kHidden + h * kDimHead + d];
+  const int lo = blockIdx.y * per_split;
+  int hi = lo + per_split;
+  if (hi > nchunks) hi = nchunks;
+  const float* pm = part_m + (long long)b * nchunks * kHidden + h * kDimHead + d;
   const float* pc = part_ctx + ((long long)b * nchunks * kHeads + h) * (kDimHead * kDimHead) + d * kDimHead + e;
-  float acc = 0.f;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    float w = expf(pm[(long long)ch * kHidden] - M);
-    acc = fmaf(w, pc[(long long)ch * kHeads * kDimHead * kDimHead], acc);
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int ch = lo;
+  for (; ch + 4 <= hi; ch += 4) {
+    float m0 = pm[(long long)ch * kHidden], m1 = pm[(long long)(ch + 1) * kHidden], m2 = pm[(long long)(ch + 2) * kHidden],
+          m3 = pm[(long long)(ch + 3) * kHidden];
+    float c0 = pc[(long long)ch * kHeads * 1024], c1 = pc[(long long)(ch + 1) * kHeads * 1024], c2 = pc[(long long)(ch + 2) * kHeads * 1024],
+          c3 = pc[(long long)(ch + 3) * kHeads * 1024];
+    acc0 = fmaf(expf(m0 - M), c0, acc0);
+    acc1 = fmaf(expf(m1 - M), c1, acc1);
+    acc2 = fmaf(expf(m2 - M), c2, acc2);
+    acc3 = fmaf(expf(m3 - M), c3, acc3);
   }
-  ctx[((long long)b * kHeads + h) * (kDimHead * kDimHead) + d * kDimHead + e] = acc / S;
+  for (; ch < hi; ++ch) acc0 = fmaf(expf(pm[(long long)ch * kHidden] - M), pc[(long long)ch * kHeads * 1024], acc0);
+  float* dst = ctx + ((long long)b * kHeads + h) * (kDimHead * kDimHead) + d * kDimHead + e;
+  const float v = ((acc0 + acc1) + (acc2 + acc3)) / S;
+  if (gridDim.y == 1) *dst = v;
+  else atomicAdd(dst, v);
 }
 
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
                                     float* ctx, float* colM, float* colS, hipStream_t s) {
-  hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, part_ctx, part_m, part_s, nchunks, ctx, colM, colS);
+  hipLaunchKernelGGL(attn_ctx_stats_kernel, dim3(B * kHeads), dim3(1024), 0, s, part_m, part_s, nchunks, colM, colS);
+  int nsplit = (nchunks + 31) / 32;
+  if (nsplit > 16) nsplit = 16;
+  if (nsplit < 1) nsplit = 1;
+  const int per_split = (nchunks + nsplit - 1) / nsplit;
+  nsplit = (nchunks + per_split - 1) / per_split;
+  if (nsplit > 1) {
+    hipError_t e = launch_fill(ctx, 0.f, B * kHeads * kDimHead * kDimHead, s);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(attn_ctx_accum_kernel, dim3(B * kHeads, nsplit), dim3(1024), 0, s, part_ctx, part_m, colM, colS, nchunks, per_split, ctx);
   return hipGetLastError();
 }
 

@@ -269,7 +269,8 @@ struct Buffers {
   size_t stats_count = 0;
   std::vector<float*> D, P, Q, S1, S2, QKV, CAT;
   float* U0;
-  float *part_ctx, *part_m, *part_s, *ctx, *weff;
+  float *part_ctx, *part_m, *part_s, *ctx, *weff, *colM, *colS;
+  bool tproj_ready = false;        // true when tproj already holds this evaluation's time projections
 };
 
 void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
@@ -312,6 +313,8 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
   b.part_m = A.alloc<float>(B * nch * kHidden);
   b.part_s = A.alloc<float>(B * nch * kHidden);
   b.ctx = A.alloc<float>(B * kHeads * kDimHead * kDimHead);
+  b.colM = A.alloc<float>(B * kHidden);
+  b.colS = A.alloc<float>(B * kHidden);
   b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
 }
 
@@ -480,7 +483,7 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   float* qkv = b.QKV[l];
   CK(conv1x1(e, at.qkv, in, in_ld, l, false, qkv, 3 * kHidden, nullptr, 0, nullptr, nullptr, 0, nullptr));
   CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
-  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, nullptr, nullptr, e.s));
+  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, b.colM, b.colS, e.s));
   const int bk = pick_bk(kHidden);
   CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s));
   ConvW eff;
@@ -541,7 +544,7 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   const int L = h->cfg.n_mults, F = h->cfg.n_feats, T = e.T;
   e.gn_slot = 0;
   CK(hipMemsetAsync(b.stats, 0, b.stats_count * sizeof(double), e.s));
-  CK(time_embedding(e, t, spk));
+  if (!b.tproj_ready) CK(time_embedding(e, t, spk));
   CK(launch_stack_inputs(x, Bx, mu, Bmu, n_text_uncond, h->text_uncon->buf.p, e.mask, e.Bm, b.in2, e.Bp, F, T, e.s));
 
   const float* cur = nullptr;
@@ -554,8 +557,7 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
       const ResnetW& r = d.r1;
       double* st1 = next_stats(e);
       double* st2 = next_stats(e);
-      CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], b.Q[0], e.Bp, F, T, c, e.s));
-      CK(launch_gn_stats(b.S1[0], c, e.Bp, F * T, c, st1, e.s));
+      CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], b.Q[0], st1, e.Bp, F, T, c, e.s));
       CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, true, b.S1[0], c));
       CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
       CK(gn_apply(e, b.S2[0], 0, c, st2, r.g2, r.b2, nullptr, b.Q[0], c, false, true, b.P[0], c));
@@ -600,6 +602,56 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   CK(conv3x3(e, h->final_conv3, fin, fin_ld, 0, b.S1[0], c0, stf));
   CK(gn_apply(e, b.S1[0], 0, c0, stf, h->final_g, h->final_b, nullptr, nullptr, 0, false, false, b.S1[0], c0));
   CK(launch_final_conv(b.S1[0], c0, h->final_w1->buf.p, h->final_b1->buf.p, e.mask, T, e.Bm, out, e.Bp, F, T, c0, e.s));
+  return hipSuccess;
+}
+
+// ---- time / speaker projections for a block of diffusion steps ------------------------------------------------
+// `mlp(time_emb)` of every ResnetBlock depends only on (t_i, spk_emb) (unitspeech.py:165-168, 61, 72), so the sampler
+// computes it for kTimeBlock steps at once instead of launching 24 tiny kernels per evaluation.
+constexpr int kTimeBlock = 64;
+
+inline size_t sum_res_cout(us_decoder* h) {
+  size_t c = 0;
+  for (auto& d : h->downs) c += d.r1.cout + d.r2.cout;
+  c += h->mid1.cout + h->mid2.cout;
+  for (auto& u : h->ups) c += u.r1.cout + u.r2.cout;
+  return c;
+}
+inline size_t time_block_floats(us_decoder* h, int Bp) {
+  const size_t rows = (size_t)kTimeBlock * Bp;
+  const int dim = h->cfg.dim, td = dim + h->cfg.spk_emb_dim;
+  return rows * (sum_res_cout(h) + td + 4 * dim + dim + 1) + 64 * 8;
+}
+struct TimeBlock {
+  float *t_all, *posemb, *mlp_h, *temb, *tproj;   // rows = steps * Bp
+};
+inline void plan_time_block(us_decoder* h, Arena& A, int Bp, TimeBlock& tb) {
+  const size_t rows = (size_t)kTimeBlock * Bp;
+  const int dim = h->cfg.dim, td = dim + h->cfg.spk_emb_dim;
+  tb.t_all = A.alloc<float>(rows);
+  tb.posemb = A.alloc<float>(rows * dim);
+  tb.mlp_h = A.alloc<float>(rows * 4 * dim);
+  tb.temb = A.alloc<float>(rows * td);
+  tb.tproj = A.alloc<float>(rows * sum_res_cout(h));
+}
+// steps [i0, i0+ns): t values from the host coefficient table; layout of tb.tproj: per resnet r a [ns*Bp][cout_r] block
+// starting at ns * tproj_off[r] (tproj_off from plan()): step i's rows sit at + (i-i0)*Bp*cout_r.
+inline hipError_t compute_time_block(EvalCtx& e, TimeBlock& tb, const float* coef_host, int i0, int ns, const float* spk_cfg) {
+  us_decoder* h = e.h;
+  const int dim = h->cfg.dim, S = h->cfg.spk_emb_dim, td = dim + S;
+  const int rows = ns * e.Bp;
+  for (int i = 0; i < ns; ++i) CK(launch_fill(tb.t_all + (size_t)i * e.Bp, coef_host[(size_t)(i0 + i) * 8 + 6], e.Bp, e.s));
+  CK(launch_pos_emb(tb.t_all, tb.posemb, rows, dim, h->cfg.pe_scale, e.s));
+  CK(launch_linear(tb.posemb, dim, h->mlp0_w->buf.p, h->mlp0_b->buf.p, tb.mlp_h, 4 * dim, rows, dim, 4 * dim, false, e.s));
+  CK(launch_linear(tb.mlp_h, 4 * dim, h->mlp2_w->buf.p, h->mlp2_b->buf.p, tb.temb, td, rows, 4 * dim, dim, true, e.s));
+  CK(launch_copy_rows(spk_cfg, S, e.Bp, tb.temb + dim, td, rows, S, e.s));
+  auto proj = [&](const ResnetW& r) {
+    return launch_linear(tb.temb, td, r.mlp_w->buf.p, r.mlp_b->buf.p, tb.tproj + (size_t)ns * e.b->tproj_off[r.index], r.cout, rows, td,
+                         r.cout, true, e.s);
+  };
+  for (auto& d : h->downs) { CK(proj(d.r1)); CK(proj(d.r2)); }
+  CK(proj(h->mid1)); CK(proj(h->mid2));
+  for (auto& u : h->ups) { CK(proj(u.r1)); CK(proj(u.r2)); }
   return hipSuccess;
 }
 
@@ -736,7 +788,8 @@ size_t us_sampler_workspace_bytes(us_handle h, int mb, int T, int n_cfg) {
   const size_t FT = (size_t)h->cfg.n_feats * T;
   const size_t Bp = (size_t)mb * n_cfg;
   // xt, score planes, spk rows, t, normalised spk_uncon (+ alignment slack) + one estimator workspace
-  size_t own = (mb * FT + Bp * FT + Bp * h->cfg.spk_emb_dim + Bp + h->cfg.spk_emb_dim) * sizeof(float) + 8 * 256;
+  size_t own = (mb * FT + Bp * FT + Bp * h->cfg.spk_emb_dim + Bp + h->cfg.spk_emb_dim) * sizeof(float) + 16 * 256;
+  own += time_block_floats(h, (int)Bp) * sizeof(float);
   return own + us_workspace_bytes(h, (int)Bp, T);
 }
 
@@ -831,6 +884,8 @@ int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const f
   float* spk_cfg = A.alloc<float>((size_t)mbs * n_cfg * S);
   float* tbuf = A.alloc<float>((size_t)mbs * n_cfg);
   float* spk_un = A.alloc<float>((size_t)S);
+  TimeBlock tblock;
+  plan_time_block(h, A, mbs * n_cfg, tblock);
   Buffers bufs;
   const size_t est_off = (A.off + 255) & ~size_t(255);
   if (use_s) US_HIP(h, launch_l2_normalize(h->spk_uncon->buf.p, spk_un, S, s));     // :358
@@ -852,9 +907,26 @@ int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const f
     }
     const int n_text_uncond = use_t ? mb : 0;
     EvalCtx e{h, s, &bufs, Bp, T, mask_b, mb};
+    const std::vector<size_t> base_off = bufs.tproj_off;     // per-resnet offsets of ONE evaluation (plan())
+    std::vector<int> couts(h->n_resnets, 0);
+    for (auto& d : h->downs) { couts[d.r1.index] = d.r1.cout; couts[d.r2.index] = d.r2.cout; }
+    couts[h->mid1.index] = h->mid1.cout; couts[h->mid2.index] = h->mid2.cout;
+    for (auto& u : h->ups) { couts[u.r1.index] = u.r1.cout; couts[u.r2.index] = u.r2.cout; }
+    float* eval_tproj = bufs.tproj;
+    int blk0 = 0, blk_n = 0;
     for (int i = 0; i < N; ++i) {
       const float* c = coef_host + (size_t)i * 8;
-      US_HIP(h, launch_fill(tbuf, c[6], Bp, s));
+      if (i >= blk0 + blk_n) {            // (re)fill the time-projection block
+        blk0 = i;
+        blk_n = (N - i) < kTimeBlock ? (N - i) : kTimeBlock;
+        bufs.tproj = eval_tproj;
+        bufs.tproj_off = base_off;
+        US_HIP(h, compute_time_block(e, tblock, coef_host, blk0, blk_n, spk_cfg));
+      }
+      bufs.tproj = tblock.tproj;
+      for (int r = 0; r < h->n_resnets; ++r)
+        bufs.tproj_off[r] = (size_t)blk_n * base_off[r] + (size_t)(i - blk0) * Bp * couts[r];
+      bufs.tproj_ready = true;
       US_HIP(h, estimator_eval(e, xt, mb, cond_b, mb, n_text_uncond, tbuf, spk_cfg, score, i == N / 2));
       SamplerArgs sa;
       memset(&sa, 0, sizeof sa);

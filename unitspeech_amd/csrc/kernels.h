@@ -57,8 +57,9 @@ hipError_t launch_pack_conv_weight(const float* src, float* dst, int Cout, int C
 // ---- first layer (2 input channels) ---------------------------------------------------------------
 // in2: [Bp][F][T][2] = (mu, x) already masked; writes conv3x3 (pad 1) -> y[Bp][F*T][C] and the ResnetBlock's
 // 1x1 res_conv -> r[Bp][F*T][C].  w3: reference OIHW [C][2][3][3]; w1: [C][2].
+// stats (optional, zeroed by the caller): GroupNorm(8) partial sums [Bp][8][2] of y
 hipError_t launch_first_conv(const float* in2, const float* w3, const float* b3, const float* w1, const float* b1, float* y,
-                             float* r, int Bp, int F, int T, int C, hipStream_t s);
+                             float* r, double* stats, int Bp, int F, int T, int C, hipStream_t s);
 // Builds in2 from planar inputs.  x: [Bx][F][T], mu: [Bmu][F][T], mu_feat: [F] (text_uncon, broadcast over T);
 // item b' reads x[b' % Bx], mask[b' % Bm] and mu_feat when b' < n_text_uncond, else mu[b' % Bmu].
 hipError_t launch_stack_inputs(const float* x, int Bx, const float* mu, int Bmu, int n_text_uncond, const float* mu_feat,
@@ -91,7 +92,7 @@ hipError_t launch_final_conv(const float* h, int ld, const float* w, const float
 // Stage 3: fold ctx into to_out: weff[B] packed [1][128/bk][C][bk], weff[c][h*32+d] = sum_e Wout[c][h*32+e]*ctx[h][d][e].
 hipError_t launch_attn_ctx_partial(const float* qkv, int B, int n, float* part_ctx, float* part_m, float* part_s, int nchunks,
                                    hipStream_t s);
-// colM / colS (optional, [B][128]): the softmax column max and sum-exp, kept for the backward pass
+// colM / colS ([B][128], required): the softmax column max and sum-exp (also kept for the backward pass)
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
                                     float* ctx, float* colM, float* colS, hipStream_t s);
 hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s);

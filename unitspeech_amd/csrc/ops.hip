@@ -67,8 +67,10 @@ constexpr int FC_TW = 32;
 __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict__ in2, const float* __restrict__ w3,
                                                          const float* __restrict__ b3, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, float* __restrict__ y, float* __restrict__ r,
-                                                         int F, int T, int C) {
+                                                         double* __restrict__ stats, int F, int T, int C) {
   __shared__ float patch[3][FC_TW + 2][2];
+  __shared__ float gred[kGroups][2];
+  if (threadIdx.x < kGroups * 2) gred[threadIdx.x >> 1][threadIdx.x & 1] = 0.f;
   const int b = blockIdx.z, f = blockIdx.y, t0 = blockIdx.x * FC_TW;
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * (FC_TW + 2) * 2; i += 256) {
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 18; ++i) w[i] = w3[co * 18 + i];   // OIHW: [co][ci][ky][kx]
     const float bb = b3[co], r0 = w1[co * 2], r1 = w1[co * 2 + 1], rb = b1[co];
+    float s1 = 0.f, s2 = 0.f;
     for (int xx = 0; xx < FC_TW; ++xx) {
       if (t0 + xx >= T) break;
       float acc = bb;
@@ -95,15 +98,26 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
           for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[ci * 9 + ky * 3 + kx], patch[ky][xx + kx][ci], acc);
       long long p = ((long long)b * F + f) * T + t0 + xx;
       y[p * C + co] = acc;
+      s1 += acc;
+      s2 += acc * acc;
       r[p * C + co] = fmaf(r1, patch[1][xx + 1][1], fmaf(r0, patch[1][xx + 1][0], rb));
     }
+    if (stats) {
+      atomicAdd(&gred[co / (C / kGroups)][0], s1);
+      atomicAdd(&gred[co / (C / kGroups)][1], s2);
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    if (threadIdx.x < kGroups * 2)
+      atomicAdd(&stats[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], (double)gred[threadIdx.x >> 1][threadIdx.x & 1]);
   }
 }
 
 hipError_t launch_first_conv(const float* in2, const float* w3, const float* b3, const float* w1, const float* b1, float* y,
-                             float* r, int Bp, int F, int T, int C, hipStream_t s) {
+                             float* r, double* stats, int Bp, int F, int T, int C, hipStream_t s) {
   dim3 grid((T + FC_TW - 1) / FC_TW, F, Bp);
-  hipLaunchKernelGGL(first_conv_kernel, grid, dim3(256), 0, s, in2, w3, b3, w1, b1, y, r, F, T, C);
+  hipLaunchKernelGGL(first_conv_kernel, grid, dim3(256), 0, s, in2, w3, b3, w1, b1, y, r, stats, F, T, C);
   return hipGetLastError();
 }
 
