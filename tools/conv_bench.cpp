@@ -131,7 +131,9 @@ int main(int argc, char** argv) {
   Shape shapes[] = {{"L0 3x3 128->128", 3, 80, 1024, 128, 128, 9}, {"L1 3x3 256->256", 3, 40, 512, 256, 256, 9},
                     {"L2 3x3 512->512", 3, 20, 256, 512, 512, 9}, {"L3 3x3 1024->1024", 3, 10, 128, 1024, 1024, 9},
                     {"L3 3x3 2048->512", 3, 10, 128, 2048, 512, 9}, {"L0 1x1 128->384", 3, 80, 1024, 128, 384, 1},
-                    {"L0 1x1 128->128", 3, 80, 1024, 128, 128, 1}};
+                    {"L0 1x1 128->128", 3, 80, 1024, 128, 128, 1},
+                    {"K1152 small-spatial", 48, 20, 256, 128, 128, 9}, {"K1152 W=128 rows", 3, 640, 128, 128, 128, 9},
+                    {"K2304 L0-spatial", 3, 80, 1024, 256, 128, 9}, {"1x1 K=1024 ->128", 3, 80, 1024, 1024, 128, 1}};
   float* zeros; CK(hipMalloc(&zeros, 16384)); CK(hipMemset(zeros, 0, 16384));
   for (auto& sh : shapes) {
     size_t n_in = (size_t)sh.B * sh.H * sh.W * sh.Cin, n_out = (size_t)sh.B * sh.H * sh.W * sh.Cout;

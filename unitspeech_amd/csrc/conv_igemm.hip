@@ -249,13 +249,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const float* add_b = a.add ? a.add + (long long)b * a.Hout * a.Wout * a.add_ld : nullptr;
   const float* om_b = a.omask ? a.omask + (long long)(b % a.omask_bmod) * a.omask_ld : nullptr;
   float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};
+  // pixel coordinates are only needed for sub-grid launches and for the output mask; rows of one 32-row block are
+  // m_base + {0..31}, so one division per block and a carry per row replace a division per row
+  const bool need_xy = !dense || om_b != nullptr;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
+    const int m_base = m0 + wm * WM + mb * 32;
+    int yb = 0, xb = 0;
+    if (need_xy) { yb = m_base / a.Ws; xb = m_base - yb * a.Ws; }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * WM + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int dr = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int m = m_base + dr;
       if (m < Ms) {
-        const int yy = m / a.Ws, xx = m - yy * a.Ws;
+        int yy = yb, xx = xb + dr;
+        if (need_xy) while (xx >= a.Ws) { xx -= a.Ws; ++yy; }
         const int ox = a.ox0 + xx * a.ostep;
         const long long pix = dense ? (long long)m : (long long)(a.oy0 + yy * a.ostep) * a.Wout + ox;
         const float om = om_b ? om_b[ox * a.omask_step] : 1.f;
