@@ -114,7 +114,7 @@ def main():
     for _ in range(a.warmup):
         out = step()
     torch.cuda.synchronize()
-    eng = model._get_engine()
+    eng = model._sync(device)          # creates the handle / pushes the weights when no warm-up step has run yet
     eng.lib.us_profile_enable(eng.handle, 1)
     eng.lib.us_profile_read(eng.handle, None, None, None, None, None, 1)
 

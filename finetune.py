@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Speaker adaptation with the HIP decoder: the reference's `finetune.py` command line (:177-191) and inner loop (:131-165:
+`decoder.fine_tune` -> `loss.backward()` -> `clip_grad_norm_(1)` -> `Adam(lr=2e-5).step()`), decoder swapped for
+`unitspeech_amd.UnitSpeech`.
+
+  default       the reference's pre-steps (speaker embedder, unit extractor, unit encoder, mel extraction; finetune.py:47-128)
+                come from a checkout of the reference given with --reference_root and stay on the stock PyTorch path.
+  --synthetic   seeded synthetic decoder weights and a synthetic (mel, units, durations, speaker embedding) tuple: runs the
+                fine-tuning loop itself (BASELINE.json configs[3]) without any downloaded model.
+Saves {"model", "spk_emb", "mel_min", "mel_max"} like finetune.py:167-173.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_state_dict
+from unitspeech_amd.util import fix_len_compatibility, generate_path, sequence_mask
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference_sample", type=str, default="reference.wav", help="Sample used to adapt the model to the speaker.")
+    ap.add_argument("--ID", type=int, default=-1, help="Unique value used to identify the finetuned decoder.")
+    ap.add_argument("--n_iters", type=int, default=500, help="Number of fine-tuning iterations.")
+    ap.add_argument("--learning_rate", type=float, default=2e-5, help="Learning rate of the optimizer during fine-tuning.")
+    ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--reference_root", type=str, default=None)
+    ap.add_argument("--out_dir", type=str, default="checkpoints/inference")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("CUDA/ROCm is not available: the HIP decoder has no CPU fallback")
+    device = torch.device("cuda", 0)
+    torch.manual_seed(args.seed)
+    import random
+    random.seed(args.seed)
+    cfg = DecoderConfig()
+    n_down = len(cfg.dim_mults) - 1
+    segment = fix_len_compatibility(2 * 22050 // 256, n_down)                 # out_size, finetune.py:40-44 (= 176)
+    decoder = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
+
+    if args.synthetic:
+        decoder.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, 0).items()})
+        g = np.random.Generator(np.random.Philox(key=args.ID & 0xffff))
+        L = 600
+        Lu = L // 3
+        mel = torch.from_numpy(g.standard_normal((1, cfg.n_feats, L), dtype=np.float32)).clamp(-1, 1).to(device)
+        cond_x = (torch.from_numpy(g.standard_normal((1, cfg.n_feats, Lu), dtype=np.float32)) * 0.5).to(device)
+        duration = torch.full((1, Lu), 3.0, device=device)
+        spk = torch.from_numpy(g.standard_normal((1, 1, cfg.spk_emb_dim), dtype=np.float32)).to(device)
+        spk_emb = spk / spk.norm()
+        mel_min, mel_max = torch.tensor(-11.5), torch.tensor(2.0)
+    else:
+        if not args.reference_root:
+            raise SystemExit("give --reference_root (reference checkout with its checkpoints) or use --synthetic")
+        raise SystemExit("non-synthetic fine-tuning needs the reference's WavLM/ECAPA speaker embedder, mHuBERT unit extractor and unit "
+                         "encoder checkpoints (finetune.py:47-128), none of which are available offline; run the pre-steps with the "
+                         "reference and pass their tensors to unitspeech_amd.UnitSpeech.fine_tune (same signature as the reference)")
+    decoder = decoder.to(device).train()
+    opt = torch.optim.Adam(decoder.parameters(), lr=args.learning_rate)                      # finetune.py:81
+    mel_lengths = torch.LongTensor([mel.shape[-1]]).to(device)
+    mel_mask = sequence_mask(mel_lengths, mel.shape[-1]).unsqueeze(1).to(mel.dtype)
+    x_mask = torch.ones(1, 1, cond_x.shape[-1], device=device)
+    attn = generate_path(duration, (x_mask.unsqueeze(-1) * mel_mask.unsqueeze(2)).squeeze(1))
+
+    t0 = time.perf_counter()
+    for it in range(args.n_iters):                                                           # finetune.py:131-165
+        loss = decoder.fine_tune(cond_x, mel, mel_mask, mel_lengths, mel.shape[-1], attn, spk_emb, segment, cfg.n_feats)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(decoder.parameters(), 1)
+        opt.step()
+        if it % 50 == 0 or it == args.n_iters - 1:
+            print(f"iter {it:4d}  diffusion loss {loss.item():.5f}")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{args.n_iters} iterations in {dt:.2f} s ({1e3 * dt / max(args.n_iters, 1):.1f} ms/iter)")
+    os.makedirs(args.out_dir, exist_ok=True)
+    path = os.path.join(args.out_dir, f"{args.ID}.pt")
+    torch.save({"model": {k: v.detach().cpu() for k, v in decoder.state_dict().items()}, "spk_emb": spk_emb.cpu(), "mel_min": mel_min,
+                "mel_max": mel_max}, path)                                                   # finetune.py:167-173
+    print(f"saved {path}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,28 @@
+"""The inference.py / finetune.py command-line mirrors run end to end in --synthetic mode (GPU)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_inference_cli_synthetic(tmp_path):
+    out = tmp_path / "sample.wav"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "inference.py"), "--synthetic", "--text", "buna ziua", "--diffusion_steps", "3",
+                        "--generated_sample_path", str(out)], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mel = np.load(str(out)[:-4] + ".mel.npy")
+    assert mel.shape[0] == 80 and mel.shape[1] > 0 and np.isfinite(mel).all()
+
+
+def test_finetune_cli_synthetic(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "finetune.py"), "--synthetic", "--n_iters", "3", "--ID", "5", "--out_dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import torch
+    ck = torch.load(tmp_path / "5.pt", map_location="cpu")
+    assert set(ck) == {"model", "spk_emb", "mel_min", "mel_max"} and len(ck["model"]) == 230
