@@ -57,10 +57,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z;
-  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  // split-K: blockIdx.x = m_tile * ksplit + ks; slice ks sums the chunks [s_lo, s_lo + S) of the ntaps * nchunk total
+  const int ks = a.ksplit > 1 ? (int)(blockIdx.x % a.ksplit) : 0;
+  const int m0 = (a.ksplit > 1 ? (int)(blockIdx.x / a.ksplit) : (int)blockIdx.x) * TM, n0 = blockIdx.y * TN;
   const int Ms = a.Hs * a.Ws;
   const int nchunk = a.Cin / BK;
-  const int S = a.ntaps * nchunk;
+  const int S_all = a.ntaps * nchunk;
+  const int s_lo = a.ksplit > 1 ? (int)(((long long)S_all * ks) / a.ksplit) : 0;
+  const int S = a.ksplit > 1 ? (int)(((long long)S_all * (ks + 1)) / a.ksplit) - s_lo : S_all;
 
   // ---- DMA source bookkeeping: this lane feeds LDS position (row = rbase + lane/CPR, chunk slot = lane%CPR) ----
   const int lrow = lane / CPR, lpos = lane % CPR;
@@ -148,9 +152,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     else if ((hsh & 3) == 3) __builtin_amdgcn_s_setprio(3);
   }
 #endif
-  int tap_n = 0, ch_n = 0;
-  setup_tap(0);
-  dma(0, 0);
+  int tap_n = s_lo / nchunk, ch_n = s_lo - tap_n * nchunk;
+  setup_tap(tap_n);
+  dma(ch_n, 0);
   if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
   __syncthreads();
 
@@ -249,6 +253,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const float* add_b = a.add ? a.add + (long long)b * a.Hout * a.Wout * a.add_ld : nullptr;
   const float* om_b = a.omask ? a.omask + (long long)(b % a.omask_bmod) * a.omask_ld : nullptr;
   float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};
+  if (a.ksplit > 1) {
+    // raw partial sums into this slice's slab [ks][B][Ms][Cout]; splitk_finish_kernel sums the slices in a fixed order and
+    // applies bias / Rezero / residual / mask / GroupNorm sums (deterministic, unlike float atomics)
+    float* slab = a.splitk_ws + (((long long)ks * a.B + b) * Ms) * a.Cout;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m < Ms) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int n = n0 + wn * 64 + nb * 32 + l32;
+            if (n < a.Cout) slab[(long long)m * a.Cout + n] = acc[mb][nb][r];
+          }
+        }
+      }
+    return;
+  }
   // pixel coordinates are only needed for sub-grid launches and for the output mask; rows of one 32-row block are
   // m_base + {0..31}, so one division per block and a carry per row replace a division per row
   const bool need_xy = !dense || om_b != nullptr;
@@ -305,6 +328,68 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+// Second half of a split-K convolution: out = epilogue(sum_ks slab[ks]) with the same epilogue as the single-pass kernel.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
+  __shared__ double s_g[kGroups][2];
+  const int b = blockIdx.y;
+  const int Ms = a.Hs * a.Ws;
+  const int C4 = a.Cout >> 2;
+  const long long total = (long long)Ms * C4;
+  if (threadIdx.x < kGroups * 2) s_g[threadIdx.x >> 1][threadIdx.x & 1] = 0.0;
+  __syncthreads();
+  // GroupNorm sums: every thread keeps fp32 partials of its own elements (fixed order), merged in fp64 (order-insensitive
+  // at fp32 resolution) -- float atomics here would make the statistics, hence the output, vary from run to run
+  float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+  int tn = -1;
+  const bool dense = (a.ostep == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Hs == a.Hout && a.Ws == a.Wout);
+  const float alpha = a.alpha ? *a.alpha : 1.f;
+  float* out_b = a.out + (long long)b * a.Hout * a.Wout * a.out_ld;
+  const float* add_b = a.add ? a.add + (long long)b * a.Hout * a.Wout * a.add_ld : nullptr;
+  const float* om_b = a.omask ? a.omask + (long long)(b % a.omask_bmod) * a.omask_ld : nullptr;
+  const long long slice = (long long)a.B * Ms * a.Cout;
+  const int cg = a.Cout / kGroups;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i % C4) * 4;
+    const int m = (int)(i / C4);
+    const float* p = a.splitk_ws + ((long long)b * Ms + m) * a.Cout + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int k = 1; k < a.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p + k * slice);
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.stats) {
+      if (tn >= 0 && tn != n) {          // (only when the grid stride is not a multiple of Cout/4: flush and restart)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          atomicAdd(&s_g[(tn + k) / cg][0], (double)t1[k]);
+          atomicAdd(&s_g[(tn + k) / cg][1], (double)t2[k]);
+          t1[k] = t2[k] = 0.f;
+        }
+      }
+      tn = n;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { t1[k] += v[k]; t2[k] += v[k] * v[k]; }
+    }
+    const int yy = m / a.Ws, xx = m - yy * a.Ws;
+    const int ox = a.ox0 + xx * a.ostep;
+    const long long pix = dense ? (long long)m : (long long)(a.oy0 + yy * a.ostep) * a.Wout + ox;
+    v *= alpha;
+    if (add_b) v += *reinterpret_cast<const f32x4*>(add_b + pix * a.add_ld + n);
+    if (om_b) v *= om_b[ox * a.omask_step];
+    *reinterpret_cast<f32x4*>(out_b + pix * a.out_ld + n) = v;
+  }
+  if (a.stats) {
+    if (tn >= 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(&s_g[(tn + k) / cg][0], (double)t1[k]);
+        atomicAdd(&s_g[(tn + k) / cg][1], (double)t2[k]);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kGroups * 2)
+      atomicAdd(&a.stats[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], s_g[threadIdx.x >> 1][threadIdx.x & 1]);
+  }
+}
+
 static size_t lds_bytes(int bk, int tm) { return (size_t)2 * (tm + TN) * bk * sizeof(float); }
 
 template <int BK, int WM>
@@ -322,8 +407,10 @@ hipError_t conv_igemm_init() {
 }
 
 static int g_tm64_threshold = -1;
+static int g_splitk = -1;
 
-hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
   if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
   if ((a.bk != 16 && a.bk != 32) || a.Cin % a.bk != 0 || a.ntaps < 1 || a.ntaps > kMaxTaps) return hipErrorInvalidValue;
   if (a.in_ld % 4 != 0) return hipErrorInvalidValue;   // 16-byte DMA pieces of the activation rows
@@ -347,7 +434,28 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     const long long wgs128 = (long long)((Ms + 127) / 128) * nt * a.B;
     tm = wgs128 < g_tm64_threshold ? 64 : 128;
   }
-  dim3 grid((Ms + tm - 1) / tm, nt, a.B);
+  // split-K for launches that cannot fill the chip (small images / short utterances / fine-tune crops): slice the
+  // taps*Cin/BK chunks over `ksplit` workgroups per tile, partial slabs in `splitk_ws`, summed by splitk_finish_kernel
+  const int mt = (Ms + tm - 1) / tm;
+  const long long tiles = (long long)mt * nt * a.B;
+  const int S_all = a.ntaps * (a.Cin / a.bk);
+  a.ksplit = 1;
+  if (g_splitk < 0) {
+    const char* e = getenv("US_SPLITK");
+    g_splitk = e ? atoi(e) : 1;
+  }
+  // The slice count depends on the per-item tile count only (never on the batch), so an utterance's result does not depend
+  // on what it is batched or sharded with (tests: ...shard_independence).
+  const long long tiles_item = (long long)mt * nt;
+  (void)tiles;
+  if (g_splitk && a.splitk_ws && tiles_item < 128 && S_all >= 8 && a.Cout % 4 == 0 && a.out_ld % 4 == 0 && (!a.add || a.add_ld % 4 == 0)) {
+    long long k = (256 + tiles_item - 1) / tiles_item;      // aim at >= 256 workgroups per item
+    if (k > S_all / 4) k = S_all / 4;                        // at least 4 chunks per slice
+    if (k > 512 / tiles_item) k = 512 / tiles_item;          // bounds the slab: k * Ms * Cout <= 512 tiles = 4 Mi floats per item
+    if (k > 32) k = 32;
+    if (k >= 2 && k * (long long)a.B * Ms * a.Cout <= a.splitk_ws_floats) a.ksplit = (int)k;
+  }
+  dim3 grid(mt * a.ksplit, nt, a.B);
   const size_t lds = lds_bytes(a.bk, tm);
   if (a.bk == 32 && tm == 128)
     hipLaunchKernelGGL((conv_igemm_kernel<32, 64>), grid, dim3(256), lds, s, a);
@@ -357,6 +465,13 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm_kernel<16, 64>), grid, dim3(256), lds, s, a);
   else
     hipLaunchKernelGGL((conv_igemm_kernel<16, 32>), grid, dim3(256), lds, s, a);
+  if (a.ksplit > 1) {
+    long long total = (long long)Ms * (a.Cout / 4);
+    int blocks = (int)((total + 1023) / 1024);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks, a.B), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -270,6 +270,8 @@ struct Buffers {
   std::vector<float*> D, P, Q, S1, S2, QKV, CAT;
   float* U0;
   float *part_ctx, *part_m, *part_s, *ctx, *weff, *colM, *colS;
+  float* splitk = nullptr;         // split-K slab scratch of the conv kernel
+  size_t splitk_floats = 0;
   bool tproj_ready = false;        // true when tproj already holds this evaluation's time projections
 };
 
@@ -315,6 +317,8 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
   b.ctx = A.alloc<float>(B * kHeads * kDimHead * kDimHead);
   b.colM = A.alloc<float>(B * kHidden);
   b.colS = A.alloc<float>(B * kHidden);
+  b.splitk_floats = B * ((size_t)4 << 20);  // 4 Mi floats per item: the conv launcher's bound on its split-K slabs
+  b.splitk = A.alloc<float>(b.splitk_floats);
   b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
 }
 
@@ -355,6 +359,8 @@ ConvArgs base_args(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int H
   a.bk = w.w->bk;
   a.omask_bmod = 1;
   a.zeros = e.h->zeros;
+  a.splitk_ws = e.b->splitk;
+  a.splitk_ws_floats = (long long)e.b->splitk_floats;
   return a;
 }
 

@@ -36,6 +36,9 @@ struct ConvArgs {
   int omask_ld, omask_step, omask_bmod;
   int bk;                // 16 or 32: channel chunk the weights were packed for
   int tm;                // rows per workgroup: 128, 64 or 0 = choose from the grid size
+  int ksplit;            // set by the launcher: K slices per tile (1 = single pass)
+  float* splitk_ws;      // optional scratch for split-K partial slabs (splitk_ws_floats floats); null disables split-K
+  long long splitk_ws_floats;
   int debug;             // timing ablations for tools/conv_bench (0 in production): 1 = no DMA after the prologue,
                          // 2 = no fragment reads after the first, 4 = no barriers
   unsigned long long dy_bits, dx_bits, wtap_bits;   // 4 bits per tap: dy+8, dx+8, weight tap index
