@@ -108,8 +108,9 @@ size_t us_train_workspace_bytes(us_handle h, int B, int T);
 int us_estimator_forward_train(us_handle h, const float* x, const float* mask, const float* mu, const float* t,
                                const float* spk, float* out, int B, int T, void* workspace, size_t workspace_bytes,
                                us_stream stream);
+/* flags: bit 0 = the gradient buffers are already zero (e.g. views of one zero-filled blob): skips 228 fill launches. */
 int us_estimator_backward(us_handle h, const float* grad_out, const char* const* keys, float* const* grads, int n_grads,
-                          us_stream stream);
+                          int flags, us_stream stream);
 
 /* Sampled kernel timing for the roofline report.  When enabled, the middle evaluation of every
  * us_reverse_diffusion micro-batch (and every us_estimator_forward) brackets each implicit-GEMM convolution launch,

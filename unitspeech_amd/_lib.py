@@ -38,7 +38,7 @@ SIGNATURES = {
     "us_estimator_flops": (C.c_double, [C.c_void_p, C.c_int]),
     "us_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "us_estimator_forward_train": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "us_estimator_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "us_estimator_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
     "us_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "us_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

@@ -179,7 +179,10 @@ hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float
 hipError_t launch_first_conv_wgrad(const float* in2, const float* gy, const float* gr, int Bp, int F, int T, int C, float* gw3,
                                    float* gw1, hipStream_t s);
 hipError_t launch_add2(const float* a, int a_ld, const float* b, int b_ld, float* out, int out_ld, long long rows, int C, hipStream_t s);
+// gW/gb accumulate f(x)-weighted sums; gx (optional, pre-zeroed) accumulates gy*W WITHOUT the mish' factor of a mish-input
+// layer: call launch_mul_mish_grad(gx, x) once after all layers sharing that input have been added
 hipError_t launch_linear_bwd(const float* gy, int gy_ld, const float* W, const float* x, int x_ld, int rows, int in_dim, int out_dim,
-                             bool mish_in, float* gW, float* gb, float* gx, int gx_ld, bool accumulate_gx, hipStream_t s);
+                             bool mish_in, float* gW, float* gb, float* gx, int gx_ld, hipStream_t s);
+hipError_t launch_mul_mish_grad(float* g, int g_ld, const float* x, int x_ld, int rows, int n, hipStream_t s);
 
 }  // namespace us

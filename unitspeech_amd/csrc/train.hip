@@ -570,27 +570,53 @@ __global__ void linear_bwd_w_kernel(const float* __restrict__ gy, int gy_ld, con
   if (k == 0 && gb) atomicAdd(&gb[o], accb);
 }
 
-__global__ void linear_bwd_x_kernel(const float* __restrict__ gy, int gy_ld, const float* __restrict__ W, const float* __restrict__ x,
-                                    int x_ld, int rows, int in_dim, int out_dim, int mish_in, int accumulate, float* __restrict__ gx,
-                                    int gx_ld) {
+// gx[r][k] += sum_{o in slice} gy[r][o] * W[o][k]   (raw: the mish'(x) factor of a mish-input layer is applied once by
+// mul_mish_grad_kernel after every layer sharing that input has been accumulated)
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ gy, int gy_ld, const float* __restrict__ W, int in_dim,
+                                                           int out_dim, int per_slice, float* __restrict__ gx, int gx_ld) {
   const int r = blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= in_dim) return;
-  float acc = 0.f;
-  for (int o = 0; o < out_dim; ++o) acc += gy[(long long)r * gy_ld + o] * W[(long long)o * in_dim + k];
-  if (mish_in) acc *= mish_grad(x[(long long)r * x_ld + k]);
-  float* dst = gx + (long long)r * gx_ld + k;
-  *dst = accumulate ? *dst + acc : acc;
+  const int o0 = blockIdx.z * per_slice;
+  int o1 = o0 + per_slice;
+  if (o1 > out_dim) o1 = out_dim;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int o = o0;
+  for (; o + 4 <= o1; o += 4) {
+    a0 = fmaf(gy[(long long)r * gy_ld + o], W[(long long)o * in_dim + k], a0);
+    a1 = fmaf(gy[(long long)r * gy_ld + o + 1], W[(long long)(o + 1) * in_dim + k], a1);
+    a2 = fmaf(gy[(long long)r * gy_ld + o + 2], W[(long long)(o + 2) * in_dim + k], a2);
+    a3 = fmaf(gy[(long long)r * gy_ld + o + 3], W[(long long)(o + 3) * in_dim + k], a3);
+  }
+  for (; o < o1; ++o) a0 = fmaf(gy[(long long)r * gy_ld + o], W[(long long)o * in_dim + k], a0);
+  atomicAdd(gx + (long long)r * gx_ld + k, (a0 + a1) + (a2 + a3));
 }
 
+__global__ void mul_mish_grad_kernel(float* __restrict__ g, int g_ld, const float* __restrict__ x, int x_ld, int rows, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * n) return;
+  const int r = i / n, k = i % n;
+  g[(long long)r * g_ld + k] *= mish_grad(x[(long long)r * x_ld + k]);
+}
+
+hipError_t launch_mul_mish_grad(float* g, int g_ld, const float* x, int x_ld, int rows, int n, hipStream_t s) {
+  hipLaunchKernelGGL(mul_mish_grad_kernel, dim3((rows * n + 255) / 256), dim3(256), 0, s, g, g_ld, x, x_ld, rows, n);
+  return hipGetLastError();
+}
+
+// gx must be zeroed by the caller before the first layer accumulates into it; see linear_bwd_x_kernel for the mish' factor
 hipError_t launch_linear_bwd(const float* gy, int gy_ld, const float* W, const float* x, int x_ld, int rows, int in_dim, int out_dim,
-                             bool mish_in, float* gW, float* gb, float* gx, int gx_ld, bool accumulate_gx, hipStream_t s) {
+                             bool mish_in, float* gW, float* gb, float* gx, int gx_ld, hipStream_t s) {
   long long tot = (long long)out_dim * in_dim;
   hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gy, gy_ld, x, x_ld, rows, in_dim, out_dim,
                      mish_in ? 1 : 0, gW, gb);
-  if (gx)
-    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((in_dim + 255) / 256, rows), dim3(256), 0, s, gy, gy_ld, W, x, x_ld, rows, in_dim, out_dim,
-                       mish_in ? 1 : 0, accumulate_gx ? 1 : 0, gx, gx_ld);
+  if (gx) {
+    int nslice = (out_dim + 63) / 64;
+    if (nslice > 32) nslice = 32;
+    const int per_slice = (out_dim + nslice - 1) / nslice;
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((in_dim + 255) / 256, rows, nslice), dim3(256), 0, s, gy, gy_ld, W, in_dim, out_dim, per_slice,
+                       gx, gx_ld);
+  }
   return hipGetLastError();
 }
 

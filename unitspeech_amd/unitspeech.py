@@ -200,12 +200,19 @@ class _EstimatorFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         eng, keys, dev = ctx.eng, ctx.keys, ctx.dev
         g = _f32c(grad_out, dev)
-        grads = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, _ in ctx.param_meta]
+        # one zero-filled blob, one view per parameter: a single fill instead of one per tensor
+        sizes = [int(torch.Size(shape).numel()) for shape, _ in ctx.param_meta]
+        offs, total = [], 0
+        for sz in sizes:
+            offs.append(total)
+            total += (sz + 63) // 64 * 64          # keep every view 256-byte aligned
+        blob = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads = [blob[o:o + sz].view(shape) for o, sz, (shape, _) in zip(offs, sizes, ctx.param_meta)]
         n = len(keys)
         ckeys = (C.c_char_p * n)(*[k.encode() for k in keys])
         cptrs = (C.c_void_p * n)(*[gr.data_ptr() for gr in grads])
         with torch.cuda.device(dev):
-            rc = eng.lib.us_estimator_backward(eng.handle, _dev_ptr(g), ckeys, cptrs, n, _stream())
+            rc = eng.lib.us_estimator_backward(eng.handle, _dev_ptr(g), ckeys, cptrs, n, 1, _stream())
         _lib.check(rc, eng.handle, "us_estimator_backward")
         ctx.ws = None
         ctx.inputs = None
