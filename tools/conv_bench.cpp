@@ -133,8 +133,12 @@ int main(int argc, char** argv) {
                     {"L3 3x3 2048->512", 3, 10, 128, 2048, 512, 9}, {"L0 1x1 128->384", 3, 80, 1024, 128, 384, 1},
                     {"L0 1x1 128->128", 3, 80, 1024, 128, 128, 1},
                     {"K1152 small-spatial", 48, 20, 256, 128, 128, 9}, {"K1152 W=128 rows", 3, 640, 128, 128, 128, 9},
-                    {"K2304 L0-spatial", 3, 80, 1024, 256, 128, 9}, {"1x1 K=1024 ->128", 3, 80, 1024, 1024, 128, 1}};
+                    {"K2304 L0-spatial", 3, 80, 1024, 256, 128, 9}, {"1x1 K=1024 ->128", 3, 80, 1024, 1024, 128, 1},
+                    {"L3 1x1 1024->384", 3, 10, 128, 1024, 384, 1}, {"L3 1x1 128->1024", 3, 10, 128, 128, 1024, 1},
+                    {"L3 1x1 512->1024", 3, 10, 128, 512, 1024, 1}, {"L2 1x1 512->384", 3, 20, 256, 512, 384, 1}};
   float* zeros; CK(hipMalloc(&zeros, 16384)); CK(hipMemset(zeros, 0, 16384));
+  float* skws = nullptr; const long long skfl = 12LL << 20;
+  if (getenv("CB_SPLITK")) CK(hipMalloc(&skws, skfl * 4));
   for (auto& sh : shapes) {
     size_t n_in = (size_t)sh.B * sh.H * sh.W * sh.Cin, n_out = (size_t)sh.B * sh.H * sh.W * sh.Cout;
     size_t n_w = (size_t)sh.taps * sh.Cin * sh.Cout;
@@ -146,6 +150,7 @@ int main(int argc, char** argv) {
       a.in = in; a.in_ld = sh.Cin; a.wt = w; a.bias = bias; a.out = out; a.out_ld = sh.Cout; a.zeros = zeros;
       a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;
       a.ostep = 1; a.istride = 1; a.ntaps = sh.taps; a.bk = 32; a.tm = tm; a.omask_bmod = 1; a.debug = debug;
+      a.splitk_ws = skws; a.splitk_ws_floats = skfl;
       if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }
       else a.set_tap(0, 0, 0, 0);
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
