@@ -267,3 +267,49 @@ def test_fine_tune_step_matches_oracle_and_updates_weights(golden):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref = O.estimator_forward(sd, x.cpu(), torch.ones(1, 1, 16), x.cpu(), torch.full((1,), 0.5), g["spk_emb"])
     assert l1(out, ref) <= 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sampler edge cases: ragged batch with a fully padded item, single step, minimum length, properties at BASELINE size
+# ---------------------------------------------------------------------------------------------------------------
+def test_loop_ragged_batch_vs_oracle(tiny):
+    model, sd = tiny
+    T, N = 40, 6
+    inp = G(synthetic_inputs(TINY, 3, T, seed=31, n_steps=N, lengths=[T, 17, 0]))
+    for mb in (1, 2, 3):
+        model.micro_batch = mb
+        out = model(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), inp["spk_emb"].to(DEV), N, 1.0, 1.0,
+                    noise=inp["noise"].to(DEV))
+        ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["cond"], inp["spk_emb"], N, 1.0, 1.0, noise=inp["noise"])
+        assert l1(out, ref) <= 1e-4
+        assert out[2].abs().max().item() == 0.0                       # fully padded utterance stays zero
+        assert (out.cpu() * (1 - inp["mask"])).abs().max().item() == 0.0
+    model.micro_batch = 0
+
+
+@pytest.mark.parametrize("T,N", [(8, 1), (8, 3), (16, 2)])
+def test_loop_minimum_sizes_vs_oracle(tiny, T, N):
+    """T = 8 is the smallest legal length (fix_len_compatibility); N = 1 is a case the reference itself cannot run
+    (its `.squeeze()` turns the 1-step schedule into a 0-d tensor, unitspeech.py:344)."""
+    model, sd = tiny
+    inp = G(synthetic_inputs(TINY, 1, T, seed=41, n_steps=N))
+    out = model(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), inp["spk_emb"].to(DEV), N, 1.0, 1.0,
+                noise=inp["noise"].to(DEV))
+    ref = O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["cond"], inp["spk_emb"], N, 1.0, 1.0, noise=inp["noise"])
+    assert l1(out, ref) <= 1e-4
+
+
+def test_baseline_size_sampler_properties(full):
+    """Size-independent properties at the BASELINE shape (B=1, 80x1024, full-size weights), 2 steps:
+    determinism of the built-in generator, batch-composition independence (bit-exact), masked frames exactly zero."""
+    model, _ = full
+    T = 1024
+    inp = G(synthetic_inputs(FULL, 2, T, seed=51, lengths=[T, T - 96]))
+    args = [inp[k].to(DEV) for k in ("z", "mask", "cond", "spk_emb")]
+    a = model(*args, 2, 1.0, 1.0, rng="philox", seed=9)
+    b = model(*args, 2, 1.0, 1.0, rng="philox", seed=9)
+    assert torch.equal(a, b)
+    one = model(*(t[1:] for t in args), 2, 1.0, 1.0, rng="philox", seed=9, utt_offset=1)
+    assert torch.equal(a[1:], one)
+    assert torch.isfinite(a).all()
+    assert (a.cpu() * (1 - inp["mask"])).abs().max().item() == 0.0

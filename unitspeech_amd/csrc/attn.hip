@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void attn_ctx_stats_kernel(const float* __res
 
 __global__ __launch_bounds__(1024) void attn_ctx_accum_kernel(const float* __restrict__ part_ctx, const float* __restrict__ part_m,
                                                               const float* __restrict__ colM, const float* __restrict__ colS, int nchunks,
-                                                              int per_split, float* __restrict__ ctx) {
+                                                              int per_split, float* __restrict__ ctx, float* __restrict__ split_ws) {
   const int b = blockIdx.x / kHeads, h = blockIdx.x % kHeads;
   const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
   const float M = colM[(long long)b * kHidden + h * kDimHead + d], S = colS[(long long)b * kHidden + h * kDimHead + d];
@@ -124,25 +124,35 @@ __global__ __launch_bounds__(1024) void attn_ctx_accum_kernel(const float* __res
     acc3 = fmaf(expf(m3 - M), c3, acc3);
   }
   for (; ch < hi; ++ch) acc0 = fmaf(expf(pm[(long long)ch * kHidden] - M), pc[(long long)ch * kHeads * 1024], acc0);
-  float* dst = ctx + ((long long)b * kHeads + h) * (kDimHead * kDimHead) + d * kDimHead + e;
   const float v = ((acc0 + acc1) + (acc2 + acc3)) / S;
-  if (gridDim.y == 1) *dst = v;
-  else atomicAdd(dst, v);
+  // one slab per chunk range; attn_ctx_reduce_kernel adds them in a fixed order (float atomics would make ctx, and with it
+  // every later activation, vary from run to run)
+  float* dst = (gridDim.y == 1 ? ctx : split_ws + (long long)blockIdx.y * gridDim.x * (kDimHead * kDimHead)) +
+               ((long long)b * kHeads + h) * (kDimHead * kDimHead) + d * kDimHead + e;
+  *dst = v;
+}
+
+__global__ __launch_bounds__(1024) void attn_ctx_reduce_kernel(const float* __restrict__ split_ws, int nsplit, long long slab,
+                                                               float* __restrict__ ctx) {
+  const long long i = blockIdx.x * 1024LL + threadIdx.x;
+  float acc = split_ws[i];
+  for (int k = 1; k < nsplit; ++k) acc += split_ws[i + k * slab];
+  ctx[i] = acc;
 }
 
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
-                                    float* ctx, float* colM, float* colS, hipStream_t s) {
+                                    float* ctx, float* colM, float* colS, float* split_ws, hipStream_t s) {
   hipLaunchKernelGGL(attn_ctx_stats_kernel, dim3(B * kHeads), dim3(1024), 0, s, part_m, part_s, nchunks, colM, colS);
   int nsplit = (nchunks + 31) / 32;
-  if (nsplit > 16) nsplit = 16;
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit > kAttnMaxSplit) nsplit = kAttnMaxSplit;
+  if (nsplit < 1 || !split_ws) nsplit = 1;
   const int per_split = (nchunks + nsplit - 1) / nsplit;
   nsplit = (nchunks + per_split - 1) / per_split;
-  if (nsplit > 1) {
-    hipError_t e = launch_fill(ctx, 0.f, B * kHeads * kDimHead * kDimHead, s);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(attn_ctx_accum_kernel, dim3(B * kHeads, nsplit), dim3(1024), 0, s, part_ctx, part_m, colM, colS, nchunks, per_split, ctx);
+  hipLaunchKernelGGL(attn_ctx_accum_kernel, dim3(B * kHeads, nsplit), dim3(1024), 0, s, part_ctx, part_m, colM, colS, nchunks, per_split, ctx,
+                     split_ws);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(attn_ctx_reduce_kernel, dim3(B * kHeads), dim3(1024), 0, s, split_ws, nsplit,
+                       (long long)B * kHeads * kDimHead * kDimHead, ctx);
   return hipGetLastError();
 }
 

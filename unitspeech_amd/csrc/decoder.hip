@@ -269,7 +269,7 @@ struct Buffers {
   size_t stats_count = 0;
   std::vector<float*> D, P, Q, S1, S2, QKV, CAT;
   float* U0;
-  float *part_ctx, *part_m, *part_s, *ctx, *weff, *colM, *colS;
+  float *part_ctx, *part_m, *part_s, *ctx, *weff, *colM, *colS, *ctx_split;
   float* splitk = nullptr;         // split-K slab scratch of the conv kernel
   size_t splitk_floats = 0;
   bool tproj_ready = false;        // true when tproj already holds this evaluation's time projections
@@ -317,6 +317,7 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
   b.ctx = A.alloc<float>(B * kHeads * kDimHead * kDimHead);
   b.colM = A.alloc<float>(B * kHidden);
   b.colS = A.alloc<float>(B * kHidden);
+  b.ctx_split = A.alloc<float>((size_t)kAttnMaxSplit * B * kHeads * kDimHead * kDimHead);
   b.splitk_floats = B * ((size_t)4 << 20);  // 4 Mi floats per item: the conv launcher's bound on its split-K slabs
   b.splitk = A.alloc<float>(b.splitk_floats);
   b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
@@ -489,7 +490,7 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   float* qkv = b.QKV[l];
   CK(conv1x1(e, at.qkv, in, in_ld, l, false, qkv, 3 * kHidden, nullptr, 0, nullptr, nullptr, 0, nullptr));
   CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
-  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, b.colM, b.colS, e.s));
+  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, b.colM, b.colS, b.ctx_split, e.s));
   const int bk = pick_bk(kHidden);
   CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s));
   ConvW eff;

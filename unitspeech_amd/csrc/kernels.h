@@ -96,8 +96,10 @@ hipError_t launch_final_conv(const float* h, int ld, const float* w, const float
 hipError_t launch_attn_ctx_partial(const float* qkv, int B, int n, float* part_ctx, float* part_m, float* part_s, int nchunks,
                                    hipStream_t s);
 // colM / colS ([B][128], required): the softmax column max and sum-exp (also kept for the backward pass)
+// split_ws: scratch of kAttnMaxSplit * B * 4096 floats for the per-range slabs (null = single range)
+constexpr int kAttnMaxSplit = 16;
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
-                                    float* ctx, float* colM, float* colS, hipStream_t s);
+                                    float* ctx, float* colM, float* colS, float* split_ws, hipStream_t s);
 hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s);
 inline int attn_nchunks(int n) { return (n + 127) / 128; }
 

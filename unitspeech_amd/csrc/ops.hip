@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
                                                          const float* __restrict__ b1, float* __restrict__ y, float* __restrict__ r,
                                                          double* __restrict__ stats, int F, int T, int C) {
   __shared__ float patch[3][FC_TW + 2][2];
-  __shared__ float gred[kGroups][2];
-  if (threadIdx.x < kGroups * 2) gred[threadIdx.x >> 1][threadIdx.x & 1] = 0.f;
+  __shared__ double gred[kGroups][2];    // fp64: the merge order of the per-thread fp32 partials must not show in the result
+  if (threadIdx.x < kGroups * 2) gred[threadIdx.x >> 1][threadIdx.x & 1] = 0.0;
   const int b = blockIdx.z, f = blockIdx.y, t0 = blockIdx.x * FC_TW;
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * (FC_TW + 2) * 2; i += 256) {
@@ -105,14 +105,14 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
       r[p * C + co] = fmaf(r1, patch[1][xx + 1][1], fmaf(r0, patch[1][xx + 1][0], rb));
     }
     if (stats) {
-      atomicAdd(&gred[co / (C / kGroups)][0], s1);
-      atomicAdd(&gred[co / (C / kGroups)][1], s2);
+      atomicAdd(&gred[co / (C / kGroups)][0], (double)s1);
+      atomicAdd(&gred[co / (C / kGroups)][1], (double)s2);
     }
   }
   if (stats) {
     __syncthreads();
     if (threadIdx.x < kGroups * 2)
-      atomicAdd(&stats[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], (double)gred[threadIdx.x >> 1][threadIdx.x & 1]);
+      atomicAdd(&stats[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], gred[threadIdx.x >> 1][threadIdx.x & 1]);
   }
 }
 
