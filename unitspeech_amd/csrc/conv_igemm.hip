@@ -107,16 +107,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       const bool ok = mv[j] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
       const unsigned off = ((unsigned)(iy * a.Win + ix) * (unsigned)a.in_ld + (unsigned)achunk[j]) * 4u;
       aoff[j] = ok ? off : a_bytes;
+#ifdef US_CONV_ABLATE
+      if (a.debug & 32) aoff[j] = (unsigned)(j * 4096 + lane * 16) & 0xffff;      // every load hits one hot 64 KB window
+#endif
     }
     wtap_bytes = (unsigned)wt_i * (unsigned)nchunk * (unsigned)a.Cout * (unsigned)(BK * 4);
+#ifdef US_CONV_ABLATE
+    if (a.debug & 32) wtap_bytes = 0;
+#endif
   };
   auto dma = [&](int ch, int buf) {
     float* As = smem + buf * BUF;
     float* Bs = As + TM * BK;
-    const unsigned ach = (unsigned)ch * (unsigned)(BK * 4);
+    unsigned ach = (unsigned)ch * (unsigned)(BK * 4);
+    unsigned wb = wtap_bytes + (unsigned)ch * (unsigned)a.Cout * (unsigned)(BK * 4);
+#ifdef US_CONV_ABLATE
+    if (a.debug & 32) { ach = 0; wb = 0; }
+#endif
 #pragma unroll
     for (int j = 0; j < IA; ++j) blds16(rsrc_a, aoff[j], ach, As + (wave * IA + j) * RPI * BK);
-    const unsigned wb = wtap_bytes + (unsigned)ch * (unsigned)a.Cout * (unsigned)(BK * 4);
 #pragma unroll
     for (int j = 0; j < IB; ++j) blds16(rsrc_b, boff[j], wb, Bs + (wave * IB + j) * RPI * BK);
   };
@@ -124,7 +133,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   // Two-level accumulation: the MFMA chain (an exact fp32 fma chain) runs over 128 K-elements, then is folded into
   // `total`.  A single chain over K = 9*Cin (up to 18,432) would carry ~0.2*sqrt(K) ulp of rounding error (19 ulp
   // at K = 9,216); chunks of ~sqrt(K) bring it to ~3 ulp, on par with a blocked CPU sgemm.
-  constexpr int kFlushSteps = 128 / BK;
+#ifndef US_FLUSH_K
+#define US_FLUSH_K 128
+#endif
+  constexpr int kFlushSteps = US_FLUSH_K / BK;
   f32x16 acc[MB][2], total[MB][2];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -171,7 +183,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     fb[1] = *reinterpret_cast<const f32x4*>(base + b_row + 32 * BK + co);
     // keep the reads AHEAD of the MFMAs that follow in program order (hipcc otherwise sinks them behind the
     // MFMA block and waits for them at once, exposing the LDS latency)
+#ifndef US_NO_SCHEDBAR
     __builtin_amdgcn_sched_barrier(0);
+#endif
   };
   auto mma = [&](const f32x4* fa, const f32x4* fb) {
 #if US_PRIO_MODE == 2
@@ -221,6 +235,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       continue;
     }
 #endif
+#ifdef US_NO_DEFER
+    load_frags(fa0, fb0, base, 0);
+    load_frags(fa1, fb1, base, 1);
+    mma(fa0, fb0);
+    if (NS == 4) {
+      load_frags(fa0, fb0, base, 2);
+      mma(fa1, fb1);
+      load_frags(fa1, fb1, base, 3);
+      mma(fa0, fb0);
+    }
+    mma(fa1, fb1);
+    step_done();
+#else
     load_frags(fa0, fb0, base, 0);
     if (step > 0) {           // last sub-step of the previous chunk (fragments were read before the barrier)
       mma(fa1, fb1);
@@ -234,13 +261,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       load_frags(fa1, fb1, base, 3);
       mma(fa0, fb0);
     }
+#endif
 #ifdef US_CONV_ABLATE
     if (!(a.debug & 4))
 #endif
     __syncthreads();   // drains this wave's DMA and fragment reads (vmcnt(0), lgkmcnt(0)) and orders every wave's
                        // reads of this buffer before its next overwrite
   }
+#ifndef US_NO_DEFER
   mma(fa1, fb1);
+#endif
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
