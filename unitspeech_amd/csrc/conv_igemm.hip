@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_a =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (long long)b * a.Hin * a.Win * a.in_ld), 0, (int)a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)b * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)(a.wt_bdiv > 1 ? b / a.wt_bdiv : b) * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
 
   unsigned aoff[IA];    // per-lane byte offset of the current tap's source row chunk (>= a_bytes: reads zeros)
   unsigned wtap_bytes = 0;

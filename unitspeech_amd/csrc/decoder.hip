@@ -36,6 +36,8 @@ struct Slot {
   DevBuf buf;            // RAW: reference layout; conv kinds: packed layout
   DevBuf dg;             // conv kinds (and to_out): repack for the data-gradient GEMM [tap][Cout/bk_dg][Cin][bk_dg]
   int bk_dg = 0;
+  DevBuf wino;           // 3x3 stride-1 convs of the Winograd levels: U = G g G^T, [16][Cin/bk][Cout][bk]
+  bool want_wino = false;
   bool dg_as_1x1 = false;  // RAW [Cout][Cin][1][1] tensor that also needs a dgrad pack (attention to_out)
   float* grad = nullptr; // caller-owned gradient buffer (reference layout) for the current backward call
   bool loaded = false;
@@ -87,6 +89,7 @@ struct us_decoder {
   Slot *final_g, *final_b, *final_w1, *final_b1;
   Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
   int n_resnets = 0;
+  int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
   std::shared_ptr<void> tape; // saved-activation record of the last us_estimator_forward_train call
   std::string err;
@@ -159,6 +162,10 @@ struct us_decoder {
     r.c2 = add_conv(p + ".block2.block.0", cout, cout, 3, true);
     r.g2 = add(p + ".block2.block.1.weight", {cout});
     r.b2 = add(p + ".block2.block.1.bias", {cout});
+    if (level >= wino_min_level) {
+      if (!r.first) r.c1.w->want_wino = true;
+      r.c2.w->want_wino = true;
+    }
     r.has_res = cin != cout;
     if (r.has_res) {
       if (r.first) {
@@ -270,6 +277,7 @@ struct Buffers {
   std::vector<float*> D, P, Q, S1, S2, QKV, CAT;
   float* U0;
   float *part_ctx, *part_m, *part_s, *ctx, *weff, *colM, *colS, *ctx_split;
+  float *wino_v = nullptr, *wino_m = nullptr;   // Winograd-domain input / product tensors [16][Bp][tiles][C]
   float* splitk = nullptr;         // split-K slab scratch of the conv kernel
   size_t splitk_floats = 0;
   bool tproj_ready = false;        // true when tproj already holds this evaluation's time projections
@@ -321,6 +329,16 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
   b.splitk_floats = B * ((size_t)4 << 20);  // 4 Mi floats per item: the conv launcher's bound on its split-K slabs
   b.splitk = A.alloc<float>(b.splitk_floats);
   b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
+  // Winograd scratch: the widest input (2*C[l] channels into ups.r1) and output over the Winograd levels
+  size_t wv = 0, wm = 0;
+  for (int l = h->wino_min_level; l < L; ++l) {
+    size_t tiles = (size_t)(((F >> l) + 1) / 2) * (((T >> l) + 1) / 2);
+    size_t cin = 2 * (size_t)h->C[l], cout = h->C[l];
+    if (l > 0 && (size_t)h->C[l - 1] > cin) cin = h->C[l - 1];
+    if (16 * B * tiles * cin > wv) wv = 16 * B * tiles * cin;
+    if (16 * B * tiles * cout > wm) wm = 16 * B * tiles * cout;
+  }
+  if (wv) { b.wino_v = A.alloc<float>(wv); b.wino_m = A.alloc<float>(wm); }
 }
 
 // ---- one estimator evaluation -------------------------------------------------------------------------
@@ -381,7 +399,33 @@ hipError_t run_conv(EvalCtx& e, const ConvArgs& a) {
   return err;
 }
 
+// Winograd F(2x2,3x3) form of conv3x3 (wino.hip): V = B^T d B, 16 GEMMs M_f = V_f U_f on the implicit-GEMM kernel (the 16
+// frequencies x Bp items are its "batch", weights selected per frequency), out = A^T M A + bias with the GroupNorm sums.
+hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
+  const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  Buffers& b = *e.b;
+  hipError_t err = launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, w.cin, e.s);
+  if (err != hipSuccess) return err;
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.in = b.wino_v; a.in_ld = w.cin;
+  a.wt = w.w->wino.p; a.wt_bstride = (long long)w.cout * w.cin; a.wt_bdiv = e.Bp;
+  a.out = b.wino_m; a.out_ld = w.cout;
+  a.B = 16 * e.Bp; a.Hin = th; a.Win = tw; a.Cin = w.cin; a.Hout = th; a.Wout = tw; a.Cout = w.cout;
+  a.Hs = th; a.Ws = tw; a.ostep = 1; a.istride = 1;
+  a.bk = w.w->bk;
+  a.omask_bmod = 1;
+  a.zeros = e.h->zeros;
+  a.ntaps = 1;
+  a.set_tap(0, 0, 0, 0);
+  err = run_conv(e, a);
+  if (err != hipSuccess) return err;
+  return launch_wino_output(b.wino_m, w.b ? w.b->buf.p : nullptr, out, out_ld, stats, e.Bp, H, W, w.cout, e.s);
+}
+
 hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
+  if (w.w->wino.p && e.b->wino_v) return conv3x3_wino(e, w, in, in_ld, level, out, out_ld, stats);
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
   a.ntaps = 9;
@@ -705,6 +749,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (hipGetDevice(&h->device) != hipSuccess) { g_last_error = "no HIP device"; return US_EHIP; }
   hipError_t e = conv_igemm_init();
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
+  if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
   h->build();
   {
     int max_cin = 2 * h->C.back();
@@ -722,9 +767,13 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
       s->dg.n = s->buf.n;
       ok = hipMalloc(reinterpret_cast<void**>(&s->dg.p), s->dg.n * sizeof(float)) == hipSuccess;
     }
+    if (ok && s->want_wino) {
+      s->wino.n = (size_t)16 * s->shape[0] * s->shape[1];
+      ok = hipMalloc(reinterpret_cast<void**>(&s->wino.p), s->wino.n * sizeof(float)) == hipSuccess;
+    }
     if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); }
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); }
       return US_EHIP;
     }
   }
@@ -734,7 +783,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); }
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
@@ -772,6 +821,7 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
     case Kind::CONV_OIHW:
       US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
       US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
+      if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
       break;
     case Kind::CONVT_IOHW:
       US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));

@@ -27,6 +27,7 @@ struct ConvArgs {
   float* out;            // [B][Hout][Wout][out_ld]
   double* stats;         // optional GroupNorm partial sums [B][8][2] (sum, sumsq) of acc + bias
   long long wt_bstride;  // per-item weight stride in floats (0 = shared weights)
+  int wt_bdiv;           // item b reads the weights at wt + (b / max(wt_bdiv,1)) * wt_bstride (Winograd: one matrix per frequency)
   int in_ld, out_ld, add_ld;
   int B, Hin, Win, Cin, Hout, Wout, Cout;
   int Hs, Ws;            // output sub-grid handled by this launch
@@ -187,4 +188,18 @@ hipError_t launch_linear_bwd(const float* gy, int gy_ld, const float* W, const f
                              bool mish_in, float* gW, float* gb, float* gx, int gx_ld, hipStream_t s);
 hipError_t launch_mul_mish_grad(float* g, int g_ld, const float* x, int x_ld, int rows, int n, hipStream_t s);
 
+}  // namespace us
+
+// ---- Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the low-resolution levels (wino.hip) -----------------
+// conv3x3 = 16 independent [tiles x Cin] x [Cin x Cout] GEMMs (run by the implicit-GEMM kernel as 1x1 convolutions over
+// 16*B "items") between an input transform V = B^T d B and an output transform Y = A^T M A: 2.25x fewer MFMA FLOPs for
+// 4x-expanded intermediate tensors, which pays where activations are small next to the weights (levels >= 1).
+namespace us {
+// U[f][Cout][Cin] = (G g G^T)[f], packed per frequency like a 1x1 conv: dst[f][Cin/bk][Cout][bk]; src Conv2d OIHW 3x3
+hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s);
+// x: [B][H][W][x_ld] (C channels) -> V: [16][B][th][tw][C], th = ceil(H/2), tw = ceil(W/2); zero padding outside the image
+hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s);
+// M: [16][B][th][tw][C] -> out[B][H][W][out_ld] = A^T M A + bias; optional GroupNorm partial sums [B][8][2] of the result
+hipError_t launch_wino_output(const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
+                              hipStream_t s);
 }  // namespace us
