@@ -154,6 +154,10 @@ def main():
                     "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches_sampled": launches,
                     "conv_share_of_eval_time": (conv_ms.value / ev_ms.value) if ev_ms.value > 0 else None,
                     "sampled_eval_ms": (ev_ms.value / max(int(ev_n.value), 1)),
+                    # achieved counts the FLOPs the MFMA units EXECUTE (the Winograd GEMMs at their 2.25x reduced count);
+                    # whole_job_tflops is the direct-convolution count of SURVEY.md 8(d) over wall time, which the
+                    # Winograd levels push past what the matrix cores execute
+                    "flops_basis": "executed MFMA FLOPs per conv_igemm launch (Winograd F(2x2,3x3) GEMMs at their reduced count)",
                     "whole_job_tflops": flops_step * world / (ms_per_step * 1e-3) / 1e12}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):

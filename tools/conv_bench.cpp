@@ -122,7 +122,7 @@ static void calibrate() {
   }
 }
 
-struct Shape { const char* name; int B, H, W, Cin, Cout, taps; };
+struct Shape { const char* name; int B, H, W, Cin, Cout, taps; int wino = 0; };   // wino: B = 16 frequencies x 3 items, one weight matrix per frequency
 
 int main(int argc, char** argv) {
   int debug = argc > 1 ? atoi(argv[1]) : 0;
@@ -135,13 +135,18 @@ int main(int argc, char** argv) {
                     {"K1152 small-spatial", 48, 20, 256, 128, 128, 9}, {"K1152 W=128 rows", 3, 640, 128, 128, 128, 9},
                     {"K2304 L0-spatial", 3, 80, 1024, 256, 128, 9}, {"1x1 K=1024 ->128", 3, 80, 1024, 1024, 128, 1},
                     {"L3 1x1 1024->384", 3, 10, 128, 1024, 384, 1}, {"L3 1x1 128->1024", 3, 10, 128, 128, 1024, 1},
-                    {"L3 1x1 512->1024", 3, 10, 128, 512, 1024, 1}, {"L2 1x1 512->384", 3, 20, 256, 512, 384, 1}};
+                    {"L3 1x1 512->1024", 3, 10, 128, 512, 1024, 1}, {"L2 1x1 512->384", 3, 20, 256, 512, 384, 1},
+                    {"W1 gemm 256->256", 48, 20, 256, 256, 256, 1, 1}, {"W1 gemm 512->256", 48, 20, 256, 512, 256, 1, 1},
+                    {"W2 gemm 512->512", 48, 10, 128, 512, 512, 1, 1}, {"W3 gemm 1024->1024", 48, 5, 64, 1024, 1024, 1, 1},
+                    {"W3 gemm 2048->512", 48, 5, 64, 2048, 512, 1, 1}, {"W3 gemm 512->512", 48, 5, 64, 512, 512, 1, 1},
+                    {"W0 gemm 128->128", 48, 40, 512, 128, 128, 1, 1}};
   float* zeros; CK(hipMalloc(&zeros, 16384)); CK(hipMemset(zeros, 0, 16384));
   float* skws = nullptr; const long long skfl = 12LL << 20;
   if (getenv("CB_SPLITK")) CK(hipMalloc(&skws, skfl * 4));
   for (auto& sh : shapes) {
+    if (getenv("CB_ONLY") && !strstr(sh.name, getenv("CB_ONLY"))) continue;
     size_t n_in = (size_t)sh.B * sh.H * sh.W * sh.Cin, n_out = (size_t)sh.B * sh.H * sh.W * sh.Cout;
-    size_t n_w = (size_t)sh.taps * sh.Cin * sh.Cout;
+    size_t n_w = (size_t)sh.taps * sh.Cin * sh.Cout * (sh.wino ? 16 : 1);
     float *in, *out, *w, *bias;
     CK(hipMalloc(&in, n_in * 4)); CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&w, n_w * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
     CK(launch_fill_normal(in, n_in, 1, 1, 0)); CK(launch_fill_normal(w, n_w, 1, 2, 0)); CK(launch_fill_normal(bias, sh.Cout, 1, 3, 0));
@@ -151,6 +156,7 @@ int main(int argc, char** argv) {
       a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;
       a.ostep = 1; a.istride = 1; a.ntaps = sh.taps; a.bk = 32; a.tm = tm; a.omask_bmod = 1; a.debug = debug;
       a.splitk_ws = skws; a.splitk_ws_floats = skfl;
+      if (sh.wino) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wt_bdiv = sh.B / 16; a.splitk_ws = nullptr; }
       if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }
       else a.set_tap(0, 0, 0, 0);
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
