@@ -139,13 +139,17 @@ int main(int argc, char** argv) {
                     {"W1 gemm 256->256", 48, 20, 256, 256, 256, 1, 1}, {"W1 gemm 512->256", 48, 20, 256, 512, 256, 1, 1},
                     {"W2 gemm 512->512", 48, 10, 128, 512, 512, 1, 1}, {"W3 gemm 1024->1024", 48, 5, 64, 1024, 1024, 1, 1},
                     {"W3 gemm 2048->512", 48, 5, 64, 2048, 512, 1, 1}, {"W3 gemm 512->512", 48, 5, 64, 512, 512, 1, 1},
-                    {"W0 gemm 128->128", 48, 40, 512, 128, 128, 1, 1}};
+                    {"W0 gemm 128->128", 48, 40, 512, 128, 128, 1, 1},
+                    // wino = 2: output transform fused (B = items, H x W = tile grid, output 2H x 2W)
+                    {"F0 fused 128->128", 3, 40, 512, 128, 128, 1, 2}, {"F1 fused 256->256", 3, 20, 256, 256, 256, 1, 2},
+                    {"F1 fused 512->256", 3, 20, 256, 512, 256, 1, 2}, {"F2 fused 512->512 B24", 24, 10, 128, 512, 512, 1, 2},
+                    {"F3 fused 1024->1024 B24", 24, 5, 64, 1024, 1024, 1, 2}};
   float* zeros; CK(hipMalloc(&zeros, 16384)); CK(hipMemset(zeros, 0, 16384));
   float* skws = nullptr; const long long skfl = 12LL << 20;
   if (getenv("CB_SPLITK")) CK(hipMalloc(&skws, skfl * 4));
   for (auto& sh : shapes) {
     if (getenv("CB_ONLY") && !strstr(sh.name, getenv("CB_ONLY"))) continue;
-    size_t n_in = (size_t)sh.B * sh.H * sh.W * sh.Cin, n_out = (size_t)sh.B * sh.H * sh.W * sh.Cout;
+    size_t n_in = (size_t)sh.B * sh.H * sh.W * sh.Cin * (sh.wino == 2 ? 16 : 1), n_out = (size_t)sh.B * sh.H * sh.W * sh.Cout * (sh.wino == 2 ? 4 : 1);
     size_t n_w = (size_t)sh.taps * sh.Cin * sh.Cout * (sh.wino ? 16 : 1);
     float *in, *out, *w, *bias;
     CK(hipMalloc(&in, n_in * 4)); CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&w, n_w * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
@@ -156,7 +160,8 @@ int main(int argc, char** argv) {
       a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;
       a.ostep = 1; a.istride = 1; a.ntaps = sh.taps; a.bk = 32; a.tm = tm; a.omask_bmod = 1; a.debug = debug;
       a.splitk_ws = skws; a.splitk_ws_floats = skfl;
-      if (sh.wino) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wt_bdiv = sh.B / 16; a.splitk_ws = nullptr; }
+      if (sh.wino == 1) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wt_bdiv = sh.B / 16; a.splitk_ws = nullptr; }
+      if (sh.wino == 2) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wino_out = 1; a.ostep = 2; a.Hout = 2 * sh.H; a.Wout = 2 * sh.W; a.splitk_ws = nullptr; }
       if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }
       else a.set_tap(0, 0, 0, 0);
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -180,7 +185,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
       }
-      double fl = 2.0 * sh.B * sh.H * sh.W * (double)sh.Cin * sh.Cout * sh.taps;
+      double fl = 2.0 * sh.B * sh.H * sh.W * (double)sh.Cin * sh.Cout * sh.taps * (sh.wino == 2 ? 16 : 1);
       printf("%-20s tm=%3d debug=%d  %8.1f us  %6.1f TFLOP/s\n", sh.name, tm, debug, ms * 1e3, fl / ms / 1e9);
     }
     CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));

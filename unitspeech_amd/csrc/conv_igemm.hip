@@ -21,6 +21,7 @@
 // tensor in the reference applies `x * mask`, :54,:74); the epilogue can apply the mask to what it stores.
 // k-index convention inside an 8-channel sub-step: lane half hh supplies channels 4*hh+j to MFMA j (j=0..3) on
 // BOTH operands, so the pairs (j, 4+j) are summed by instruction j; the K-sum is complete, only its order differs.
+#include <type_traits>
 #include "kernels.h"
 
 namespace us {
@@ -40,7 +41,13 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
                                            (int)soff_bytes, 0, 0);
 }
 
-template <int BK, int WM>
+// WINO = true: Winograd-domain GEMMs with the output transform in registers.  `in` is V [16][B][th][tw][Cin], `wt` the 16
+// per-frequency matrices (wt_bstride apart); the workgroup runs its [TM tiles x TN channels] GEMM for the frequencies
+// f = 0..15 in turn and folds each M_f into the four output accumulators Y[r][q] += At[r][f/4] * At[q][f%4] * M_f
+// (coefficients 0/+-1, same order as wino_output_kernel, so both forms give the same bits); the epilogue then runs once per
+// output position (oy0, ox0) = (r, q) of the 2x2 tile with ostep = 2.  Saves the [16][B][tiles][Cout] round trip through
+// HBM and the output-transform pass, for 16x fewer (16x longer) workgroups: used where those still fill the chip.
+template <int BK, int WM, bool WINO>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int TM = 2 * WM;         // rows (pixels) per workgroup
   constexpr int MB = WM / 32;        // 32-row MFMA blocks per wave along M
@@ -90,10 +97,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
   // buffer descriptors: A = this item's activation tensor (range-checked), B = this item's packed weights
   const unsigned a_bytes = (unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.in_ld * 4u;     // < 2^31 (host-checked)
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (long long)b * a.Hin * a.Win * a.in_ld), 0, (int)a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)(a.wt_bdiv > 1 ? b / a.wt_bdiv : b) * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
+  const long long a_item = (long long)a.Hin * a.Win * a.in_ld;
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (long long)b * a_item), 0, (int)a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.wt + (WINO ? 0LL : (long long)(a.wt_bdiv > 1 ? b / a.wt_bdiv : b) * a.wt_bstride)), 0, 0x7fffffff, 0x00020000);
 
   unsigned aoff[IA];    // per-lane byte offset of the current tap's source row chunk (>= a_bytes: reads zeros)
   unsigned wtap_bytes = 0;
@@ -164,6 +171,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     else if ((hsh & 3) == 3) __builtin_amdgcn_s_setprio(3);
   }
 #endif
+  constexpr int NY = WINO ? 4 : 1;
+  f32x16 Y[NY][MB][2];       // WINO: the 2x2 output accumulators (dead otherwise)
+  if (WINO) {
+#pragma unroll
+    for (int y = 0; y < NY; ++y)
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[y][i][j][r] = 0.f;
+  }
+  const int nfreq = WINO ? 16 : 1;
+  for (int f = 0; f < nfreq; ++f) {
+  if (WINO) {
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((long long)f * a.B + b) * a_item), 0, (int)a_bytes, 0x00020000);
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)f * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
+    since_flush = 0;
+  }
   int tap_n = s_lo / nchunk, ch_n = s_lo - tap_n * nchunk;
   setup_tap(tap_n);
   dma(ch_n, 0);
@@ -275,6 +301,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
+  if (WINO) {
+    // At = [1 1 1 0; 0 1 -1 -1]: coefficient of M_f (f = 4*fi + fj) in output (r, q) is At[r][fi] * At[q][fj]
+    const int fi = f >> 2, fj = f & 3;
+    const float r0 = fi < 3 ? 1.f : 0.f, r1 = fi == 0 ? 0.f : (fi == 1 ? 1.f : -1.f);
+    const float q0 = fj < 3 ? 1.f : 0.f, q1 = fj == 0 ? 0.f : (fj == 1 ? 1.f : -1.f);
+    const float cf[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
+#pragma unroll
+    for (int y = 0; y < NY; ++y)
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[y][i][j][r] = __builtin_fmaf(cf[y], acc[i][j][r], Y[y][i][j][r]);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; total[i][j][r] = 0.f; }
+  }
+  }   // frequency loop
 
   // ---- epilogue: C/D layout of the 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
   const bool dense = (a.ostep == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Hs == a.Hout && a.Ws == a.Wout);
@@ -282,7 +330,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   float* out_b = a.out + (long long)b * a.Hout * a.Wout * a.out_ld;
   const float* add_b = a.add ? a.add + (long long)b * a.Hout * a.Wout * a.add_ld : nullptr;
   const float* om_b = a.omask ? a.omask + (long long)(b % a.omask_bmod) * a.omask_ld : nullptr;
-  float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};
+  // GroupNorm partial sums: fp32 per lane, except in the Winograd form where they are kept in fp64 so that the fused and the
+  // separate output transform (chosen by launch geometry, i.e. by the batch) agree to fp64 rounding
+  typedef typename std::conditional<WINO, double, float>::type stat_t;
+  stat_t gsum[2] = {0, 0}, gsq[2] = {0, 0};
 #ifdef US_CONV_ABLATE
   if (a.debug & 8) {       // timing ablation: no epilogue at all (keep the accumulators alive)
     float keep = 0.f;
@@ -323,6 +374,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   float* tr = smem + wave * (32 * 36);               // 32 rows x (32 + 4 pad) floats per wave
   const bool need_xy = !dense || om_b != nullptr;
   const int trow = lane >> 3, tc4 = (lane & 7) * 4;  // read-back role: row trow + 8k, channels tc4..tc4+3
+  // WINO with an odd image height / width: the last tile row / column has output positions outside the image
+  const bool edge = WINO && (((a.Hout | a.Wout) & 1) != 0);
+#pragma unroll
+  for (int yi = 0; yi < NY; ++yi) {
+  const f32x16 (&A)[MB][2] = WINO ? Y[yi] : acc;
+  const int oy0 = WINO ? (yi >> 1) : a.oy0, ox0 = WINO ? (yi & 1) : a.ox0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m_base = m0 + wm * WM + mb * 32;
@@ -336,10 +393,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float v = acc[mb][nb][r] + bv;
-          if (m < Ms && n < a.Cout) { gsum[nb] += v; gsq[nb] += v * v; }
-          tr[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + l32] = acc[mb][nb][r];
+          const int dr = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int m = m_base + dr;
+          const float v = A[mb][nb][r] + bv;
+          bool ok = m < Ms && n < a.Cout;
+          if (edge) {
+            const int yy = m / a.Ws, xx = m - yy * a.Ws;
+            ok = ok && (oy0 + 2 * yy < a.Hout) && (ox0 + 2 * xx < a.Wout);
+          }
+          if (ok) { gsum[nb] += (stat_t)v; gsq[nb] += (stat_t)(v * v); }
+          tr[dr * 36 + l32] = A[mb][nb][r];
         }
       }
       const int n = ncol + tc4;
@@ -353,8 +416,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         if (m < Ms && n < a.Cout) {
           int yy = yb, xx = xb + dr;
           if (need_xy) while (xx >= a.Ws) { xx -= a.Ws; ++yy; }
-          const int ox = a.ox0 + xx * a.ostep;
-          const long long pix = dense ? (long long)m : (long long)(a.oy0 + yy * a.ostep) * a.Wout + ox;
+          const int ox = ox0 + xx * a.ostep;
+          const int oy = oy0 + yy * a.ostep;
+          if (edge && (oy >= a.Hout || ox >= a.Wout)) continue;
+          const long long pix = dense ? (long long)m : (long long)oy * a.Wout + ox;
           v = (v + b4) * alpha;
           if (add_b) v += *reinterpret_cast<const f32x4*>(add_b + pix * a.add_ld + n);
           if (om_b) v *= om_b[ox * a.omask_step];
@@ -363,12 +428,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
+  }   // output positions
   if (a.stats) {
     // GroupNorm(8) partial sums of the conv output (pre-alpha/add/mask); Cout/8 is a power of two (host-checked)
     const int cg = a.Cout / kGroups;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      float s1 = gsum[nb], s2 = gsq[nb];
+      stat_t s1 = gsum[nb], s2 = gsq[nb];
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       const int seg = cg < 32 ? cg : 32;
@@ -450,18 +516,20 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
 
 static size_t lds_bytes(int bk, int tm) { return (size_t)2 * (tm + TN) * bk * sizeof(float); }
 
-template <int BK, int WM>
+template <int BK, int WM, bool WINO>
 static hipError_t set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, WM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, WM, WINO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_bytes(BK, 2 * WM));
 }
 
 hipError_t conv_igemm_init() {
   hipError_t e;
-  if ((e = set_attr<32, 64>()) != hipSuccess) return e;
-  if ((e = set_attr<32, 32>()) != hipSuccess) return e;
-  if ((e = set_attr<16, 64>()) != hipSuccess) return e;
-  return set_attr<16, 32>();
+  if ((e = set_attr<32, 64, false>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 32, false>()) != hipSuccess) return e;
+  if ((e = set_attr<16, 64, false>()) != hipSuccess) return e;
+  if ((e = set_attr<16, 32, false>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 32, true>()) != hipSuccess) return e;
+  return set_attr<16, 32, true>();
 }
 
 static int g_tm64_threshold = -1;
@@ -489,6 +557,13 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const int Ms = a.Hs * a.Ws;
   const int nt = (a.Cout + TN - 1) / TN;
   int tm = a.tm;
+  if (a.wino_out) {
+    // fused Winograd output transform: ntaps = 1, ostep = 2, Hs x Ws = tile grid, Hout x Wout = image, no split-K
+    if (a.ntaps != 1 || a.ostep != 2 || a.istride != 1 || a.add || a.alpha || a.omask) return hipErrorInvalidValue;
+    if (2 * a.Hs < a.Hout || 2 * a.Ws < a.Wout) return hipErrorInvalidValue;
+    tm = 64;
+    a.splitk_ws = nullptr;
+  }
   if (tm == 0) {
     const long long wgs128 = (long long)((Ms + 127) / 128) * nt * a.B;
     tm = wgs128 < g_tm64_threshold ? 64 : 128;
@@ -516,14 +591,19 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   }
   dim3 grid(mt * a.ksplit, nt, a.B);
   const size_t lds = lds_bytes(a.bk, tm);
-  if (a.bk == 32 && tm == 128)
-    hipLaunchKernelGGL((conv_igemm_kernel<32, 64>), grid, dim3(256), lds, s, a);
+  if (a.wino_out) {
+    if (a.bk == 32)
+      hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true>), grid, dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL((conv_igemm_kernel<16, 32, true>), grid, dim3(256), lds, s, a);
+  } else if (a.bk == 32 && tm == 128)
+    hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false>), grid, dim3(256), lds, s, a);
   else if (a.bk == 32)
-    hipLaunchKernelGGL((conv_igemm_kernel<32, 32>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<32, 32, false>), grid, dim3(256), lds, s, a);
   else if (tm == 128)
-    hipLaunchKernelGGL((conv_igemm_kernel<16, 64>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<16, 64, false>), grid, dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<16, 32>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<16, 32, false>), grid, dim3(256), lds, s, a);
   if (a.ksplit > 1) {
     long long total = (long long)Ms * (a.Cout / 4);
     int blocks = (int)((total + 1023) / 1024);

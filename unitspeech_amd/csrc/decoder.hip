@@ -90,7 +90,8 @@ struct us_decoder {
   Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
   int n_resnets = 0;
   bool wino_fuse_gn = false; // US_WINO_FUSE_GN=1: evaluate block1's gn_apply inside block2's Winograd input transform (measured neutral)
-  int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
+  long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
+  int wino_min_level = 0;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
   std::shared_ptr<void> tape; // saved-activation record of the last us_estimator_forward_train call
   std::string err;
@@ -412,15 +413,38 @@ hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, 
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.in = b.wino_v; a.in_ld = w.cin;
-  a.wt = w.w->wino.p; a.wt_bstride = (long long)w.cout * w.cin; a.wt_bdiv = e.Bp;
-  a.out = b.wino_m; a.out_ld = w.cout;
-  a.B = 16 * e.Bp; a.Hin = th; a.Win = tw; a.Cin = w.cin; a.Hout = th; a.Wout = tw; a.Cout = w.cout;
-  a.Hs = th; a.Ws = tw; a.ostep = 1; a.istride = 1;
+  a.wt = w.w->wino.p; a.wt_bstride = (long long)w.cout * w.cin;
+  a.Hin = th; a.Win = tw; a.Cin = w.cin; a.Cout = w.cout;
+  a.Hs = th; a.Ws = tw; a.istride = 1;
   a.bk = w.w->bk;
   a.omask_bmod = 1;
   a.zeros = e.h->zeros;
   a.ntaps = 1;
   a.set_tap(0, 0, 0, 0);
+  // Output transform inside the GEMM kernel (one workgroup walks the 16 frequencies of its tile) when that still leaves
+  // enough workgroups for the chip; otherwise 16x more, shorter workgroups and a separate transform pass.  Both forms add in
+  // the same order, so the choice (which depends on the batch) does not change a single bit of the result.
+  const long long fused_wgs = (long long)((th * tw + 63) / 64) * ((w.cout + 127) / 128) * e.Bp;
+  if (fused_wgs >= e.h->wino_fuse_min_wgs) {
+    a.wino_out = 1;
+    a.B = e.Bp; a.Hout = H; a.Wout = W; a.ostep = 2;
+    a.out = out; a.out_ld = out_ld;
+    a.bias = w.b ? w.b->buf.p : nullptr;
+    a.stats = stats;
+    us_decoder* h = e.h;
+    if (!h->prof_active) return launch_conv_igemm(a, e.s);
+    us_decoder::ProfRec r;
+    r.a = h->prof_event(); r.b = h->prof_event(); r.kind = 0;
+    r.flops = 2.0 * 16 * e.Bp * (double)th * tw * w.cout * (double)w.cin;
+    (void)hipEventRecord(r.a, e.s);
+    err = launch_conv_igemm(a, e.s);
+    (void)hipEventRecord(r.b, e.s);
+    h->prof_pending.push_back(r);
+    return err;
+  }
+  a.wt_bdiv = e.Bp;
+  a.out = b.wino_m; a.out_ld = w.cout;
+  a.B = 16 * e.Bp; a.Hout = th; a.Wout = tw; a.ostep = 1;
   err = run_conv(e, a);
   if (err != hipSuccess) return err;
   return launch_wino_output(b.wino_m, w.b ? w.b->buf.p : nullptr, out, out_ld, stats, e.Bp, H, W, w.cout, e.s);
@@ -761,6 +785,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
+  if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS")) h->wino_fuse_min_wgs = atoll(wf);
   h->build();
   {
     int max_cin = 2 * h->C.back();

@@ -38,6 +38,7 @@ struct ConvArgs {
   int bk;                // 16 or 32: channel chunk the weights were packed for
   int tm;                // rows per workgroup: 128, 64 or 0 = choose from the grid size
   int ksplit;            // set by the launcher: K slices per tile (1 = single pass)
+  int wino_out;          // 1: `in` = V [16][B][Hs][Ws][Cin], `wt` = 16 matrices wt_bstride apart; Winograd output transform in the kernel
   float* splitk_ws;      // optional scratch for split-K partial slabs (splitk_ws_floats floats); null disables split-K
   long long splitk_ws_floats;
   int debug;             // timing ablations for tools/conv_bench (0 in production): 1 = no DMA after the prologue,

@@ -133,15 +133,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   if (threadIdx.x < kGroups * 2) s_g[threadIdx.x >> 1][threadIdx.x & 1] = 0.0;
   __syncthreads();
   // a thread keeps one channel quad (grid stride is a multiple of C/4 for the power-of-two widths of the U-Net)
-  float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+  // fp64 per-thread partials (see conv_igemm_kernel<.., true>: both forms must agree to fp64 rounding)
+  double t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
   int tc = -1;
   auto flush = [&]() {
     if (tc >= 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        atomicAdd(&s_g[(tc + k) / cg][0], (double)t1[k]);
-        atomicAdd(&s_g[(tc + k) / cg][1], (double)t2[k]);
-        t1[k] = t2[k] = 0.f;
+        atomicAdd(&s_g[(tc + k) / cg][0], t1[k]);
+        atomicAdd(&s_g[(tc + k) / cg][1], t2[k]);
+        t1[k] = t2[k] = 0;
       }
     }
   };
@@ -156,20 +157,32 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int q = 0; q < 4; ++q) m[r][q] = *reinterpret_cast<const f32x4*>(mb + (long long)(r * 4 + q) * plane);
-    // s = A^T m (2 x 4), y = s A (2 x 2)
-    f32x4 s0[4], s1[4];
+    // Y = A^T M A, accumulated frequency by frequency in the order f = 0..15 with coefficients At[r][f/4] * At[q][f%4]
+    // (At = [1 1 1 0; 0 1 -1 -1]) -- the same sequence of additions as the fused form inside conv_igemm_kernel<.., true>,
+    // so a result does not depend on which form a launch geometry selects
+    f32x4 y[2][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      s0[q] = m[0][q] + m[1][q] + m[2][q];
-      s1[q] = m[1][q] - m[2][q] - m[3][q];
-    }
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+          for (int fj = 0; fj < 4; ++fj) {
+            const int ci = r == 0 ? (fi < 3 ? 1 : 0) : (fi == 0 ? 0 : (fi == 1 ? 1 : -1));
+            const int cj = q == 0 ? (fj < 3 ? 1 : 0) : (fj == 0 ? 0 : (fj == 1 ? 1 : -1));
+            if (ci * cj == 1) acc += m[fi][fj];
+            if (ci * cj == -1) acc -= m[fi][fj];
+          }
+        y[r][q] = acc;
+      }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + c);
-    f32x4 y[2][2];
-    y[0][0] = s0[0] + s0[1] + s0[2] + bv;
-    y[0][1] = s0[1] - s0[2] - s0[3] + bv;
-    y[1][0] = s1[0] + s1[1] + s1[2] + bv;
-    y[1][1] = s1[1] - s1[2] - s1[3] + bv;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) y[r][q] += bv;
     if (stats && tc != c) { flush(); tc = c; }
     float* ob = out + (long long)b * H * W * out_ld + c;
 #pragma unroll
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
           *reinterpret_cast<f32x4*>(ob + ((long long)oy * W + ox) * out_ld) = y[r][q];
           if (stats) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { t1[k] += y[r][q][k]; t2[k] += y[r][q][k] * y[r][q][k]; }
+            for (int k = 0; k < 4; ++k) { t1[k] += (double)y[r][q][k]; t2[k] += (double)(y[r][q][k] * y[r][q][k]); }
           }
         }
       }
