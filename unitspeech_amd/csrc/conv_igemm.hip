@@ -183,15 +183,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) Y[y][i][j][r] = 0.f;
   }
-  const int nfreq = WINO ? 16 : 1;
-  for (int f = 0; f < nfreq; ++f) {
-  if (WINO) {
+  // WINO: the 16 frequencies form ONE software-pipelined sequence of 16 * nchunk steps (the DMA of a frequency's first chunk
+  // is in flight while the previous frequency's last chunk is multiplied), so a K = Cin of 128 does not drain the pipeline
+  // 16 times per workgroup.
+  auto setup_freq = [&](int f) {
     rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((long long)f * a.B + b) * a_item), 0, (int)a_bytes, 0x00020000);
     rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)f * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
+  };
+  auto fold = [&](int f) {
+    // At = [1 1 1 0; 0 1 -1 -1]: coefficient of M_f (f = 4*fi + fj) in output (r, q) is At[r][fi] * At[q][fj]
+    const int fi = f >> 2, fj = f & 3;
+    const float r0 = fi < 3 ? 1.f : 0.f, r1 = fi == 0 ? 0.f : (fi == 1 ? 1.f : -1.f);
+    const float q0 = fj < 3 ? 1.f : 0.f, q1 = fj == 0 ? 0.f : (fj == 1 ? 1.f : -1.f);
+    const float cf[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] += total[i][j];
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[y][i][j][r] = __builtin_fmaf(cf[y], acc[i][j][r], Y[y][i][j][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; total[i][j][r] = 0.f; }
+      }
     since_flush = 0;
-  }
-  int tap_n = s_lo / nchunk, ch_n = s_lo - tap_n * nchunk;
-  setup_tap(tap_n);
+  };
+  const int S_run = WINO ? 16 * nchunk : S;      // steps of this workgroup's pipeline
+  int tap_n = s_lo / nchunk, ch_n = s_lo - tap_n * nchunk;   // WINO: tap_n counts frequencies
+  if (WINO) setup_freq(0);
+  setup_tap(WINO ? 0 : tap_n);
   dma(ch_n, 0);
   if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
   __syncthreads();
@@ -242,10 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
   };
 
-  for (int step = 0; step < S; ++step) {
-    const bool has_next = step + 1 < S;
+  for (int step = 0; step < S_run; ++step) {
+    const bool has_next = step + 1 < S_run;
     if (has_next) {
-      if (ch_n == 0) setup_tap(tap_n);
+      if (ch_n == 0) {
+        if (WINO) setup_freq(tap_n);
+        else setup_tap(tap_n);
+      }
 #ifdef US_CONV_ABLATE
       if (!(a.debug & 1))
 #endif
@@ -273,11 +298,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
     mma(fa1, fb1);
     step_done();
+    if (WINO && (step + 1) % nchunk == 0) fold(step / nchunk);
 #else
     load_frags(fa0, fb0, base, 0);
     if (step > 0) {           // last sub-step of the previous chunk (fragments were read before the barrier)
       mma(fa1, fb1);
       step_done();
+      if (WINO && step % nchunk == 0) fold(step / nchunk - 1);     // ... which completed a frequency
     }
     load_frags(fa1, fb1, base, 1);
     mma(fa0, fb0);
@@ -296,33 +323,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 #ifndef US_NO_DEFER
   mma(fa1, fb1);
+  if (WINO) fold(15);
 #endif
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
-  if (WINO) {
-    // At = [1 1 1 0; 0 1 -1 -1]: coefficient of M_f (f = 4*fi + fj) in output (r, q) is At[r][fi] * At[q][fj]
-    const int fi = f >> 2, fj = f & 3;
-    const float r0 = fi < 3 ? 1.f : 0.f, r1 = fi == 0 ? 0.f : (fi == 1 ? 1.f : -1.f);
-    const float q0 = fj < 3 ? 1.f : 0.f, q1 = fj == 0 ? 0.f : (fj == 1 ? 1.f : -1.f);
-    const float cf[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
-#pragma unroll
-    for (int y = 0; y < NY; ++y)
-#pragma unroll
-      for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) Y[y][i][j][r] = __builtin_fmaf(cf[y], acc[i][j][r], Y[y][i][j][r]);
+  if (!WINO) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; total[i][j][r] = 0.f; }
+      for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
   }
-  }   // frequency loop
 
   // ---- epilogue: C/D layout of the 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
   const bool dense = (a.ostep == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Hs == a.Hout && a.Ws == a.Wout);

@@ -235,6 +235,7 @@ struct us_decoder {
     mid_attn = add_attn("estimator.mid_attn", C[L - 1], L - 1);
     mid2 = add_resnet("estimator.mid_block2", C[L - 1], C[L - 1], L - 1);
     final_conv3 = add_conv("estimator.final_block.block.0", cfg.dim, cfg.dim, 3, true);
+    if (wino_min_level <= 0) final_conv3.w->want_wino = true;
     final_g = add("estimator.final_block.block.1.weight", {cfg.dim});
     final_b = add("estimator.final_block.block.1.bias", {cfg.dim});
     final_w1 = add("estimator.final_conv.weight", {1, cfg.dim, 1, 1});
