@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_state_dict
+from unitspeech_amd import DecoderConfig, FusedAdam, UnitSpeech, synthetic_state_dict
 from unitspeech_amd.util import generate_path, sequence_mask
 
 
@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--frames", type=int, default=600, help="length of the reference utterance's mel")
     ap.add_argument("--segment", type=int, default=176, help="out_size: fix_len_compatibility(2*22050//256)")
     ap.add_argument("--check", type=int, default=0, help="compare the first K losses with the CPU oracle (slow)")
+    ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
+                    help="fused: HIP clip+Adam in 3 launches (unitspeech_amd.FusedAdam); torch: clip_grad_norm_ + torch.optim.Adam")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = DecoderConfig()
@@ -32,7 +34,8 @@ def main():
     model = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     model = model.to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=2e-5)
+    fused = a.optimizer == "fused"
+    opt = (FusedAdam if fused else torch.optim.Adam)(model.parameters(), lr=2e-5)
 
     g = np.random.Generator(np.random.Philox(key=2024))
     L, Lu = a.frames, a.frames // 3
@@ -51,8 +54,11 @@ def main():
         loss = model.fine_tune(cond_x_d, y_d, y_mask_d, y_len_d, L, attn_d, spk_d, a.segment, cfg.n_feats)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
-        opt.step()
+        if fused:
+            opt.step(max_norm=1)
+        else:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
+            opt.step()
         return loss
 
     random.seed(0); torch.manual_seed(0)
@@ -66,7 +72,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
     res = {"metric": "fine-tune seconds/iteration (B=1, 176-frame crop, fwd+bwd+clip+Adam)", "value": dt, "unit": "s/iter",
-           "iters": a.iters, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": loss.item()}
+           "optimizer": a.optimizer, "iters": a.iters, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": loss.item()}
 
     if a.check > 0:
         # same python/torch draws replayed on the CPU oracle (fresh weights, same optimiser)

@@ -19,7 +19,7 @@ import time
 import numpy as np
 import torch
 
-from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_state_dict
+from unitspeech_amd import DecoderConfig, FusedAdam, UnitSpeech, synthetic_state_dict
 from unitspeech_amd.util import fix_len_compatibility, generate_path, sequence_mask
 
 
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--ID", type=int, default=-1, help="Unique value used to identify the finetuned decoder.")
     ap.add_argument("--n_iters", type=int, default=500, help="Number of fine-tuning iterations.")
     ap.add_argument("--learning_rate", type=float, default=2e-5, help="Learning rate of the optimizer during fine-tuning.")
+    ap.add_argument("--torch_optimizer", action="store_true", help="clip_grad_norm_ + torch.optim.Adam instead of the HIP clip+Adam")
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--reference_root", type=str, default=None)
     ap.add_argument("--out_dir", type=str, default="checkpoints/inference")
@@ -63,7 +64,8 @@ def main():
                          "encoder checkpoints (finetune.py:47-128), none of which are available offline; run the pre-steps with the "
                          "reference and pass their tensors to unitspeech_amd.UnitSpeech.fine_tune (same signature as the reference)")
     decoder = decoder.to(device).train()
-    opt = torch.optim.Adam(decoder.parameters(), lr=args.learning_rate)                      # finetune.py:81
+    # finetune.py:81 uses torch.optim.Adam; FusedAdam is the same update (clip + Adam) in three HIP launches
+    opt = (torch.optim.Adam if args.torch_optimizer else FusedAdam)(decoder.parameters(), lr=args.learning_rate)
     mel_lengths = torch.LongTensor([mel.shape[-1]]).to(device)
     mel_mask = sequence_mask(mel_lengths, mel.shape[-1]).unsqueeze(1).to(mel.dtype)
     x_mask = torch.ones(1, 1, cond_x.shape[-1], device=device)
@@ -74,8 +76,11 @@ def main():
         loss = decoder.fine_tune(cond_x, mel, mel_mask, mel_lengths, mel.shape[-1], attn, spk_emb, segment, cfg.n_feats)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(decoder.parameters(), 1)
-        opt.step()
+        if args.torch_optimizer:
+            torch.nn.utils.clip_grad_norm_(decoder.parameters(), 1)
+            opt.step()
+        else:
+            opt.step(max_norm=1)
         if it % 50 == 0 or it == args.n_iters - 1:
             print(f"iter {it:4d}  diffusion loss {loss.item():.5f}")
     torch.cuda.synchronize()

@@ -121,6 +121,21 @@ int us_profile_enable(us_handle h, int enable);
 int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* conv_launches, double* eval_ms,
                     int64_t* evals, int reset);
 
+/* Gradient clipping + Adam over all parameter tensors in three launches.  Replaces torch.nn.utils.clip_grad_norm_(params, max_norm)
+ * followed by torch.optim.Adam(lr, betas, eps, weight_decay=0).step()  (reference finetune.py:163-165, train_STEP1.py).
+ *   p, g, m, v  device arrays [n_tensors] of device pointers: parameter, gradient, exp_avg, exp_avg_sq (fp32, same numel)
+ *   numel       device [n_tensors]
+ *   blk_tensor, blk_off  device [n_blocks]: block i works on elements [blk_off[i], blk_off[i] + 4096) of tensor blk_tensor[i]
+ *   lr, beta1, beta2, eps  python-double hyper-parameters; 1 - beta, lr / (1 - beta1^step), sqrt(1 - beta2^step) are evaluated
+ *               in double and rounded to fp32 once, as torch.optim.Adam's scalar arguments are
+ *   step        1-based Adam step
+ *   max_norm    > 0: total L2 norm over all gradients, g *= min(1, max_norm / (norm + 1e-6)) in place first; <= 0: no clipping
+ *   partial     device scratch, n_blocks + 2 floats; on return partial[n_blocks] = total norm, partial[n_blocks+1] = coefficient
+ * Enqueues on `stream`, never synchronises. */
+int us_clip_adam_step(void* const* p, void* const* g, void* const* m, void* const* v, const int64_t* numel,
+                      const int32_t* blk_tensor, const int64_t* blk_off, int n_tensors, int n_blocks, double lr, double beta1,
+                      double beta2, double eps, int step, float max_norm, float* partial, us_stream stream);
+
 /* Last error message of this handle (or of the library when h == NULL). */
 const char* us_last_error(us_handle h);
 

@@ -239,13 +239,18 @@ def test_loss_and_gradients_vs_reference_autograd(golden, tag):
     assert abs(gn - float(g["grad_norm"])) <= 1e-4 * float(g["grad_norm"])
 
 
-def test_fine_tune_step_matches_oracle_and_updates_weights(golden):
-    """One `fine_tune` call + Adam step (finetune.py:131-165) on the tiny config: same loss as the reference golden,
-    and a second forward sees the updated weights."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_fine_tune_step_matches_oracle_and_updates_weights(golden, fused):
+    """One full fine-tune iteration (finetune.py:131-165: fine_tune -> backward -> clip_grad_norm_(1) -> Adam) on the tiny
+    config against the reference goldens: loss, total gradient norm, clipped gradients and updated parameters; with torch's
+    optimiser and with the HIP clip+Adam (`FusedAdam.step(max_norm=1)`); a second forward sees the updated weights."""
     import random
+    from unitspeech_amd import FusedAdam
     g = G(golden("finetune_tiny"))
+    a = golden("finetune_tiny_adam")
     model = make_model(TINY).train()
-    opt = torch.optim.Adam(model.parameters(), lr=2e-5)
+    start = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt = (FusedAdam if fused else torch.optim.Adam)(model.parameters(), lr=2e-5)
     random.seed(int(g["py_seed"]))
     orig_rand = torch.rand
     torch.rand = lambda *a, **k: g["t_draw"].to(DEV)
@@ -257,16 +262,56 @@ def test_fine_tune_step_matches_oracle_and_updates_weights(golden):
         torch.rand = orig_rand
     assert abs(loss.item() - float(g["loss"])) <= 2e-6
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
-    before = model.estimator.final_conv.weight.detach().clone()
-    opt.step()
-    assert not torch.equal(before, model.estimator.final_conv.weight.detach())
+    if fused:
+        opt.step(max_norm=1)
+        norm = float(opt.last_grad_norm)
+    else:
+        norm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1))
+        opt.step()
+    assert abs(norm - float(a["grad_norm"])) <= 1e-4 * float(a["grad_norm"])
+    params = dict(model.named_parameters())
+    for i, k in enumerate([str(x) for x in a["keys"]]):
+        gr, pr = torch.from_numpy(np.asarray(a[f"grad_{i}"])), torch.from_numpy(np.asarray(a[f"param_{i}"]))
+        assert (params[k].grad.cpu() - gr).abs().max() <= 2e-4 * gr.abs().max() + 1e-9, k      # clipped in place
+        d_ref, d_got = pr - start[k].cpu(), params[k].detach().cpu() - start[k].cpu()
+        assert (d_got - d_ref).abs().max() <= 4e-7, k              # the first Adam step moves every element by ~lr = 2e-5
     with torch.no_grad():          # the engine must pick the new weights up
         x = torch.zeros(1, 80, 16, device=DEV)
         out = model.estimator(x, torch.ones(1, 1, 16, device=DEV), x, torch.full((1,), 0.5, device=DEV), g["spk_emb"].to(DEV))
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref = O.estimator_forward(sd, x.cpu(), torch.ones(1, 1, 16), x.cpu(), torch.full((1,), 0.5), g["spk_emb"])
     assert l1(out, ref) <= 2e-6
+
+
+def test_fused_adam_matches_torch_adam_over_steps():
+    """HIP clip+Adam vs torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the same device: odd sizes, a 4-byte-aligned view,
+    three steps with fresh gradients (bias corrections), clipping active and inactive."""
+    from unitspeech_amd import FusedAdam
+    gen = torch.Generator().manual_seed(5)
+    base = torch.randn(100003 + 1, generator=gen)
+    shapes = [(1,), (7,), (4096,), (4097,), (64, 33, 3, 3), (1, 1, 256)]
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, s in enumerate(shapes)]
+        ps.append(torch.nn.Parameter(base.to(DEV)[1:]))            # storage offset 1: not 16-byte aligned
+        return ps
+    pa, pb = make(), make()
+    oa, ob = torch.optim.Adam(pa, lr=2e-5), FusedAdam(pb, lr=2e-5)
+    for step in range(3):
+        scale = [3.0, 1e-3, 1.0][step]                              # norm >> 1, << 1, ~
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            gr = (torch.randn(x.shape, generator=torch.Generator().manual_seed(100 * step + i)) * scale).to(DEV)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        na = torch.nn.utils.clip_grad_norm_(pa, 1)
+        oa.step()
+        ob.step(max_norm=1)
+        assert abs(float(na) - float(ob.last_grad_norm)) <= 1e-5 * float(na)
+        for x, y in zip(pa, pb):
+            assert (x.grad - y.grad).abs().max() <= 1e-6 * x.grad.abs().max() + 1e-12
+            assert (x.detach() - y.detach()).abs().max() <= 1e-7          # updates are ~2e-5: 0.5 %
+            sa, sb = oa.state[x], ob.state[y]
+            assert (sa["exp_avg"] - sb["exp_avg"]).abs().max() <= 1e-6 * sa["exp_avg"].abs().max() + 1e-12
+            assert (sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max() <= 1e-6 * sa["exp_avg_sq"].abs().max() + 1e-20
+            assert int(sb["step"]) == step + 1
 
 
 # ---------------------------------------------------------------------------------------------------------------

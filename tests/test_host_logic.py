@@ -47,6 +47,16 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         m.forward(z, torch.ones(1, 1, 8), z, torch.zeros(1, 1, 8), 2, 1.0, 1.0, noise=torch.zeros(2, 1, 80, 8))
 
 
+def test_fused_adam_refuses_cpu_parameters_and_unsupported_options():
+    from unitspeech_amd import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FusedAdam([p], lr=1e-3).step(max_norm=1)
+    with pytest.raises(ValueError):
+        FusedAdam([p], lr=1e-3, weight_decay=0.1)
+
+
 def test_submodules_are_parameter_containers_only():
     m = UnitSpeech(80, 16, [1, 2], 0.05, 20.0, 1000, 8)
     with pytest.raises(RuntimeError, match="fused HIP decoder"):

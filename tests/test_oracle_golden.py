@@ -143,6 +143,32 @@ def test_fine_tune_segment_and_loss(golden, sd_tiny):
     assert abs(loss.item() - float(g["loss"])) <= 1e-6
 
 
+def test_fine_tune_iteration_clip_and_adam_vs_reference(golden, sd_tiny):
+    """G9: oracle loss -> torch autograd -> clip_grad_norm_(1) -> Adam(lr=2e-5) reproduces the reference's gradient norm,
+    clipped gradients and updated parameters (finetune.py:163-165)."""
+    g = T(golden("finetune_tiny"))
+    a = golden("finetune_tiny_adam")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd_tiny.items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=2e-5)
+    random.seed(int(g["py_seed"]))
+    y_cut, y_cut_mask, cond_y = O.fine_tune_segment(g["cond_x"], g["y"], g["y_mask"], g["y_lengths"], g["y"].shape[-1],
+                                                    g["attn"], int(g["segment_size"]), 80)
+    t = torch.clamp(g["t_draw"], 1e-5, 1.0 - 1e-5)
+    loss, _ = O.loss_t(sd, y_cut, y_cut_mask, cond_y, t, g["spk_emb"], g["z_draw"], 80)
+    loss.backward()
+    with_grad = [v for v in sd.values() if v.grad is not None]
+    norm = torch.nn.utils.clip_grad_norm_(with_grad, 1)
+    assert abs(float(norm) - float(a["grad_norm"])) <= 1e-5 * float(a["grad_norm"])
+    grads = {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}
+    opt.step()
+    for i, k in enumerate([str(x) for x in a["keys"]]):
+        gr, pr = torch.from_numpy(np.asarray(a[f"grad_{i}"])), torch.from_numpy(np.asarray(a[f"param_{i}"]))
+        assert (grads[k] - gr).abs().max() <= 2e-5 * gr.abs().max() + 1e-9, k
+        # first Adam step moves every element by ~lr: compare the UPDATE, not the parameter
+        d_ref, d_got = pr - sd_tiny[k], sd[k].detach() - sd_tiny[k]
+        assert (d_got - d_ref).abs().max() <= 2e-7, k           # 1 % of lr = 2e-5
+
+
 def test_helpers():
     assert O.fix_len_compatibility(172, 3) == 176 and O.fix_len_compatibility(176, 3) == 176
     m = O.sequence_mask(torch.LongTensor([3, 5]), 6)

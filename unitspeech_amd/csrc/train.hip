@@ -104,10 +104,127 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// LDS-staged form for channel counts that are multiples of 128 (every conv of the full-size U-Net except the 2-channel first
+// layer): workgroup tile 128 (co) x 128 (ci), 4 waves of 64 x 64, pixels in stages of 32 rows staged by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`, one wave instruction = 2 pixel rows x 128 channels, out-of-image taps and rows past the
+// chunk read zeros through the descriptor's range check), double-buffered.  32 FLOP per LDS byte instead of one global load
+// per MFMA operand.
+constexpr int kWgKP = 32;
+__device__ __forceinline__ void wg_blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff_bytes, float* lds_dst_wave_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, (int)voff_bytes, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];      // 2 stages x (A [32][128] + B [32][128])
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, hh = lane >> 5;
+  const int Ms = a.Hs * a.Ws;
+  const int chunks_per_item = (Ms + a.chunk - 1) / a.chunk;
+  const int b = blockIdx.x / chunks_per_item;
+  const int m_lo = (blockIdx.x % chunks_per_item) * a.chunk;
+  int m_hi = m_lo + a.chunk;
+  if (m_hi > Ms) m_hi = Ms;
+  const int nci = a.Cin / 128;
+  const int co0 = (blockIdx.y / nci) * 128, ci0 = (blockIdx.y % nci) * 128;
+  const int tap = blockIdx.z;
+  const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
+  const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
+  const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);
+  const unsigned gy_bytes = (unsigned)a.Hout * (unsigned)a.Wout * (unsigned)a.gy_ld * 4u;
+  const unsigned x_bytes = (unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.x_ld * 4u;
+  const __amdgpu_buffer_rsrc_t rsrc_g =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.gy + (long long)b * a.Hout * a.Wout * a.gy_ld), 0, (int)gy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.Hin * a.Win * a.x_ld), 0, (int)x_bytes, 0x00020000);
+
+  // this lane's DMA role: instruction j of this wave covers stage rows wave*8 + 2j + (lane>>5), channels (lane&31)*4..+3
+  const int lrow = lane >> 5, lch = (lane & 31) * 4;
+  auto dma = [&](int stage_m0, int buf) {
+    float* As = wsm + buf * (2 * kWgKP * 128);
+    float* Bs = As + kWgKP * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 8 + 2 * j;
+      const int m = stage_m0 + r + lrow;
+      unsigned goff = gy_bytes, xoff = x_bytes;      // out of range: zeros
+      if (m < m_hi) {
+        const int yy = m / a.Ws, xx = m - yy * a.Ws;
+        goff = ((unsigned)((a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * (unsigned)a.gy_ld + (unsigned)(co0 + lch)) * 4u;
+        const int iy = yy * a.istride + dy, ix = xx * a.istride + dx;
+        if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
+          xoff = ((unsigned)(iy * a.Win + ix) * (unsigned)a.x_ld + (unsigned)(ci0 + lch)) * 4u;
+      }
+      wg_blds16(rsrc_g, goff, As + r * 128);
+      wg_blds16(rsrc_x, xoff, Bs + r * 128);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nstage = (m_hi - m_lo + kWgKP - 1) / kWgKP;
+  dma(m_lo, 0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    if (st + 1 < nstage) dma(m_lo + (st + 1) * kWgKP, (st + 1) & 1);
+    const float* As = wsm + (st & 1) * (2 * kWgKP * 128);
+    const float* Bs = As + kWgKP * 128;
+    // lane half hh takes stage rows 16*hh + k: any pairing of the 32 rows into 16 two-row MFMA steps gives the same sum
+    const float* ap = As + (16 * hh) * 128 + wm * 64 + l32;
+    const float* bp = Bs + (16 * hh) * 128 + wn * 64 + l32;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float a0 = ap[k * 128], a1 = ap[k * 128 + 32];
+      const float b0 = bp[k * 128], b1 = bp[k * 128 + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* gw = a.gw + (long long)b * a.gw_bstride + (long long)wt_i * a.Cout * a.Cin;
+  const bool single = chunks_per_item == 1 && (a.B == 1 || a.gw_bstride != 0);    // the only writer of these elements
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int ci = ci0 + wn * 64 + j * 32 + l32;
+        float* dst = gw + (long long)co * a.Cin + ci;
+        if (single) *dst += acc[i][j][r];
+        else atomicAdd(dst, acc[i][j][r]);
+      }
+}
+
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
   if (a.chunk % 8 != 0 || a.chunk <= 0) return hipErrorInvalidValue;
   const int Ms = a.Hs * a.Ws;
+  static int use_lds = -1;
+  if (use_lds < 0) { const char* e = getenv("US_WGRAD_LDS"); use_lds = e ? atoi(e) : 1; }
+  if (use_lds && a.Cout % 128 == 0 && a.Cin % 128 == 0 && a.gy_ld % 4 == 0 && a.x_ld % 4 == 0 &&
+      (long long)a.Hout * a.Wout * a.gy_ld * 4 < (1LL << 31) && (long long)a.Hin * a.Win * a.x_ld * 4 < (1LL << 31)) {
+    static bool attr_set = false;
+    const int lds = 2 * 2 * kWgKP * 128 * (int)sizeof(float);
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    dim3 g2(a.B * ((Ms + a.chunk - 1) / a.chunk), (a.Cout / 128) * (a.Cin / 128), a.ntaps);
+    hipLaunchKernelGGL(wgrad_lds_kernel, g2, dim3(256), lds, s, a);
+    return hipGetLastError();
+  }
   dim3 grid(a.B * ((Ms + a.chunk - 1) / a.chunk), ((a.Cout + 63) / 64) * ((a.Cin + 63) / 64), a.ntaps);
   hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, a);
   return hipGetLastError();
