@@ -856,9 +856,11 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
         US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk_dg, st));
       break;
     case Kind::CONV_OIHW:
-      US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
-      US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
+      // a conv that runs in the Winograd domain never reads its direct-form pack (conv3x3 takes the Winograd branch whenever
+      // wino.p is set; every workspace plan of this handle then has the V/M scratch)
       if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
+      else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
+      US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
       break;
     case Kind::CONVT_IOHW:
       US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));

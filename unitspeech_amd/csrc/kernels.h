@@ -143,6 +143,7 @@ struct WgradArgs {
   int B, Hin, Win, Cin, Hout, Wout, Cout;
   int Hs, Ws, oy0, ox0, ostep, istride, ntaps;
   int chunk;             // output pixels per workgroup (multiple of 8)
+  int overwrite;         // 1: gw holds garbage; legal only when every element has exactly one writer (launch_wgrad_single_writer)
   unsigned long long dy_bits, dx_bits, wtap_bits;
   void set_tap(int i, int dy, int dx, int wtap) {
     dy_bits |= (unsigned long long)(dy + 8) << (4 * i);
@@ -151,6 +152,9 @@ struct WgradArgs {
   }
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+// true when launch_wgrad(a) gives every gw element exactly one writing workgroup (LDS kernel, one pixel chunk per item, one item
+// or per-item gw): the caller may then skip zeroing gw and set a.overwrite
+bool launch_wgrad_single_writer(const WgradArgs& a);
 hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s);
 hipError_t launch_pack_dgrad_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk, hipStream_t s);
 hipError_t launch_colsum(const float* g, int ld, long long rows, int C, const float* scale, float* out, hipStream_t s);

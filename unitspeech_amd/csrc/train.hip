@@ -201,19 +201,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
         const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const int ci = ci0 + wn * 64 + j * 32 + l32;
         float* dst = gw + (long long)co * a.Cin + ci;
-        if (single) *dst += acc[i][j][r];
+        if (single) *dst = a.overwrite ? acc[i][j][r] : *dst + acc[i][j][r];
         else atomicAdd(dst, acc[i][j][r]);
       }
+}
+
+static bool wgrad_use_lds(const WgradArgs& a) {
+  static int use_lds = -1;
+  if (use_lds < 0) { const char* e = getenv("US_WGRAD_LDS"); use_lds = e ? atoi(e) : 1; }
+  return use_lds && a.Cout % 128 == 0 && a.Cin % 128 == 0 && a.gy_ld % 4 == 0 && a.x_ld % 4 == 0 &&
+         (long long)a.Hout * a.Wout * a.gy_ld * 4 < (1LL << 31) && (long long)a.Hin * a.Win * a.x_ld * 4 < (1LL << 31);
+}
+
+bool launch_wgrad_single_writer(const WgradArgs& a) {
+  const int Ms = a.Hs * a.Ws;
+  return wgrad_use_lds(a) && a.chunk >= Ms && (a.B == 1 || a.gw_bstride != 0);
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
   if (a.chunk % 8 != 0 || a.chunk <= 0) return hipErrorInvalidValue;
   const int Ms = a.Hs * a.Ws;
-  static int use_lds = -1;
-  if (use_lds < 0) { const char* e = getenv("US_WGRAD_LDS"); use_lds = e ? atoi(e) : 1; }
-  if (use_lds && a.Cout % 128 == 0 && a.Cin % 128 == 0 && a.gy_ld % 4 == 0 && a.x_ld % 4 == 0 &&
-      (long long)a.Hout * a.Wout * a.gy_ld * 4 < (1LL << 31) && (long long)a.Hin * a.Win * a.x_ld * 4 < (1LL << 31)) {
+  if (a.overwrite && !launch_wgrad_single_writer(a)) return hipErrorInvalidValue;
+  if (wgrad_use_lds(a)) {
     static bool attr_set = false;
     const int lds = 2 * 2 * kWgKP * 128 * (int)sizeof(float);
     if (!attr_set) {

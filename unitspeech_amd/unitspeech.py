@@ -130,6 +130,7 @@ class _Engine:
         self.handle = C.c_void_p()
         self.device = None
         self.versions = {}
+        self._key_meta = {}         # key -> (bytes key, ctypes shape array, shape)
         self.workspace = None
 
     def _create(self, device: torch.device):
@@ -158,14 +159,23 @@ class _Engine:
         """Push every tensor whose storage or version changed since the last call."""
         self._create(device)
         with torch.cuda.device(device):
+            stream = _stream()
+            load = self.lib.us_decoder_load_weight
             for key, t in named_tensors:
                 tag = (t.data_ptr(), t._version, t.device)
                 if self.versions.get(key) == tag:
                     continue
-                src = _f32c(t.detach(), device)
-                shape = (C.c_int64 * src.dim())(*src.shape)
-                _lib.check(self.lib.us_decoder_load_weight(self.handle, key.encode(), _dev_ptr(src), shape, src.dim(), _stream()),
-                           self.handle, f"load_weight({key})")
+                if t.dtype == torch.float32 and t.device == device and t.is_contiguous():
+                    src = t                      # the usual case: no temporary, no dispatcher round trip
+                else:
+                    src = _f32c(t.detach(), device)
+                meta = self._key_meta.get(key)
+                if meta is None or meta[2] != tuple(src.shape):
+                    meta = (key.encode(), (C.c_int64 * src.dim())(*src.shape), tuple(src.shape))
+                    self._key_meta[key] = meta
+                rc = load(self.handle, meta[0], src.data_ptr(), meta[1], len(meta[2]), stream)
+                if rc != 0:
+                    _lib.check(rc, self.handle, f"load_weight({key})")
                 self.versions[key] = tag
                 del src   # stream-ordered: the caching allocator keeps the block alive for queued work on this stream
 
