@@ -53,3 +53,34 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, out_dir):
+    """Data-parallel step on two CPU ranks: each rank's gradients = rank-dependent values; after allreduce_gradients every
+    rank holds the mean, with the blob-resident gradients moved by one collective and the loose ones by a second."""
+    from unitspeech_amd.sharding import allreduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = [(4, 3), (7,), (2, 2, 2), (5,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    blob = torch.zeros(64 * 3)
+    offs = [0, 64, 128]
+    for i, (p, o) in enumerate(zip(params[:3], offs)):                 # three gradients are views into the blob ...
+        p.grad = blob[o:o + p.numel()].view(p.shape)
+        p.grad.fill_(float((rank + 1) * (i + 1)))
+    params[3].grad = torch.full((5,), float(10 * (rank + 1)))         # ... one lives on its own
+    params.append(torch.nn.Parameter(torch.zeros(3)))                   # and one has no gradient at all
+    n = allreduce_gradients(params, world, blob=blob)
+    got = [p.grad.clone() for p in params[:4]]
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), np.concatenate([g.reshape(-1).numpy() for g in got] + [np.array([n], np.float32)]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"g{k}.npy") for k in range(world)]
+    want = np.concatenate([np.full(12, 1.5), np.full(7, 3.0), np.full(8, 4.5), np.full(5, 15.0), [2.0]]).astype(np.float32)
+    for k in range(world):
+        np.testing.assert_allclose(r[k], want, rtol=0, atol=0)           # mean of ranks 1x and 2x; 2 collectives

@@ -129,6 +129,7 @@ class _Engine:
         self.cfg = cfg
         self.handle = C.c_void_p()
         self.device = None
+        self.last_grad_blob = None
         self.versions = {}
         self._key_meta = {}         # key -> (bytes key, ctypes shape array, shape)
         self.workspace = None
@@ -226,6 +227,7 @@ class _EstimatorFn(torch.autograd.Function):
         _lib.check(rc, eng.handle, "us_estimator_backward")
         ctx.ws = None
         ctx.inputs = None
+        eng.last_grad_blob = blob               # data-parallel training all-reduces this one buffer (sharding.allreduce_gradients)
         return (None, None, None, None, None, None, None, None, *[gr.to(dt) for gr, (_, dt) in zip(grads, ctx.param_meta)])
 
 
