@@ -190,24 +190,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((long long)f * a.B + b) * a_item), 0, (int)a_bytes, 0x00020000);
     rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)f * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
   };
+  // a frequency whose K = Cin fits one accumulation chain never touches `total`
+  const bool two_level = !WINO || nchunk > kFlushSteps;
   auto fold = [&](int f) {
-    // At = [1 1 1 0; 0 1 -1 -1]: coefficient of M_f (f = 4*fi + fj) in output (r, q) is At[r][fi] * At[q][fj]
+    // At = [1 1 1 0; 0 1 -1 -1]: coefficient of M_f (f = 4*fi + fj) in output (r, q) is At[r][fi] * At[q][fj]; 7 of the 16
+    // frequencies feed one output, 6 feed two, 4 feed four: zero coefficients are skipped (wave-uniform branches)
     const int fi = f >> 2, fj = f & 3;
     const float r0 = fi < 3 ? 1.f : 0.f, r1 = fi == 0 ? 0.f : (fi == 1 ? 1.f : -1.f);
     const float q0 = fj < 3 ? 1.f : 0.f, q1 = fj == 0 ? 0.f : (fj == 1 ? 1.f : -1.f);
     const float cf[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
+    if (two_level) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] += total[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) total[i][j][r] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < NY; ++y) {
+      if (cf[y] != 0.f) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[y][i][j][r] = __builtin_fmaf(cf[y], acc[i][j][r], Y[y][i][j][r]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] += total[i][j];
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int y = 0; y < NY; ++y)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) Y[y][i][j][r] = __builtin_fmaf(cf[y], acc[i][j][r], Y[y][i][j][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; total[i][j][r] = 0.f; }
-      }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     since_flush = 0;
   };
   const int S_run = WINO ? 16 * nchunk : S;      // steps of this workgroup's pipeline
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #endif
   };
   auto step_done = [&]() {
-    if (++since_flush == kFlushSteps) {
+    if (two_level && ++since_flush == kFlushSteps) {
       since_flush = 0;
 #pragma unroll
       for (int i = 0; i < MB; ++i)
