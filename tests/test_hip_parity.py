@@ -90,6 +90,48 @@ def test_estimator_ragged_lengths_vs_oracle(tiny, T):
     assert out[2].abs().max().item() == 0.0            # fully padded item
 
 
+def _model_with_env(cfg, **env):
+    """A fresh handle created under the given environment (the library reads its tuning switches at us_decoder_create)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        m = make_model(cfg)
+        with torch.no_grad():      # creates the handle and uploads the weights now, while the environment is in place
+            x = torch.zeros(1, 80, 8, device=DEV)
+            m.estimator(x, torch.ones(1, 1, 8, device=DEV), x, torch.full((1,), 0.5, device=DEV), torch.zeros(1, 1, cfg.spk_emb_dim, device=DEV))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return m
+
+
+def test_winograd_forms_agree_bitwise_and_match_direct_convolution(tiny):
+    """The three executions of a 3x3 convolution -- Winograd with the output transform inside the GEMM kernel, Winograd with
+    separate transform passes, direct implicit GEMM -- on a ragged input whose level-3 width is odd (partial last tile):
+    the two Winograd forms agree bit for bit (the library picks between them by launch size, i.e. by batch), the direct form
+    agrees to rounding, and all match the CPU oracle."""
+    _, sd = tiny
+    T = 200                                                                   # widths 200 / 100 / 50 / 25
+    inp = G(synthetic_inputs(TINY, 3, T, seed=31, lengths=[T, T - 13, 64]))
+    t = torch.tensor([0.21, 0.55, 0.93])
+    args = [inp[k].to(DEV) for k in ("z", "mask", "cond")] + [t.to(DEV), inp["spk_emb"].to(DEV)]
+    outs = {}
+    for name, env in (("fused", {"US_WINO_FUSE_MIN_WGS": 1}), ("separate", {"US_WINO_FUSE_MIN_WGS": 10 ** 9}),
+                      ("direct", {"US_WINO_MIN_LEVEL": 99}), ("default", {})):
+        m = _model_with_env(TINY, **env)
+        with torch.no_grad():
+            outs[name] = m.estimator(*args).cpu()
+    assert torch.equal(outs["fused"], outs["separate"])
+    assert torch.equal(outs["default"], outs["fused"])
+    ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["cond"], t, inp["spk_emb"])
+    for name, o in outs.items():
+        assert l1(o, ref) <= 2e-6, name
+    assert l1(outs["direct"], outs["fused"]) <= 1e-6
+
+
 @pytest.mark.parametrize("w", ["11", "10", "01", "00"])
 def test_loop_tiny_cfg_variants(golden, tiny, w):
     model, _ = tiny

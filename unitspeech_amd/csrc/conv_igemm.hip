@@ -585,7 +585,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   int tm = a.tm;
   if (a.wino_out) {
     // fused Winograd output transform: ntaps = 1, ostep = 2, Hs x Ws = tile grid, Hout x Wout = image, no split-K
-    if (a.ntaps != 1 || a.ostep != 2 || a.istride != 1 || a.add || a.alpha || a.omask) return hipErrorInvalidValue;
+    if (a.ntaps != 1 || a.ostep != 2 || a.istride != 1 || a.alpha) return hipErrorInvalidValue;
     if (2 * a.Hs < a.Hout || 2 * a.Ws < a.Wout) return hipErrorInvalidValue;
     tm = 64;
     a.splitk_ws = nullptr;
@@ -606,8 +606,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   }
   // The slice count depends on the per-item tile count only (never on the batch), so an utterance's result does not depend
   // on what it is batched or sharded with (tests: ...shard_independence).
-  const long long tiles_item = (long long)mt * nt;
-  (void)tiles;
+  const long long tiles_item = a.splitk_by_batch ? tiles : (long long)mt * nt;
   if (g_splitk && a.splitk_ws && tiles_item < 128 && S_all >= 8 && a.Cout % 4 == 0 && a.out_ld % 4 == 0 && (!a.add || a.add_ld % 4 == 0)) {
     long long k = (256 + tiles_item - 1) / tiles_item;      // aim at >= 256 workgroups per item
     if (k > S_all / 4) k = S_all / 4;                        // at least 4 chunks per slice

@@ -37,6 +37,7 @@ struct Slot {
   DevBuf dg;             // conv kinds (and to_out): repack for the data-gradient GEMM [tap][Cout/bk_dg][Cin][bk_dg]
   int bk_dg = 0;
   DevBuf wino;           // 3x3 stride-1 convs of the Winograd levels: U = G g G^T, [16][Cin/bk][Cout][bk]
+  DevBuf wino_dg;        // ... and of the rotated, channel-swapped filter for the data gradient, [16][Cout/bk_dg][Cin][bk_dg]
   bool want_wino = false;
   bool dg_as_1x1 = false;  // RAW [Cout][Cin][1][1] tensor that also needs a dgrad pack (attention to_out)
   float* grad = nullptr; // caller-owned gradient buffer (reference layout) for the current backward call
@@ -339,7 +340,8 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
     size_t cin = 2 * (size_t)h->C[l], cout = h->C[l];
     if (l > 0 && (size_t)h->C[l - 1] > cin) cin = h->C[l - 1];
     if (16 * B * tiles * cin > wv) wv = 16 * B * tiles * cin;
-    if (16 * B * tiles * cout > wm) wm = 16 * B * tiles * cout;
+    if (16 * B * tiles * cin > wm) wm = 16 * B * tiles * cin;      // the data gradient's product tensor has the conv's Cin channels
+    (void)cout;
   }
   if (wv) { b.wino_v = A.alloc<float>(wv); b.wino_m = A.alloc<float>(wm); }
 }
@@ -353,6 +355,7 @@ struct EvalCtx {
   const float* mask;   // [Bm][T]
   int Bm;
   int gn_slot = 0;
+  int splitk_by_batch = 0;   // training contexts: see ConvArgs::splitk_by_batch
 };
 
 double* next_stats(EvalCtx& e) {
@@ -382,6 +385,7 @@ ConvArgs base_args(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int H
   a.omask_bmod = 1;
   a.zeros = e.h->zeros;
   a.splitk_ws = e.b->splitk;
+  a.splitk_by_batch = e.splitk_by_batch;
   a.splitk_ws_floats = (long long)e.b->splitk_floats;
   return a;
 }
@@ -402,22 +406,28 @@ hipError_t run_conv(EvalCtx& e, const ConvArgs& a) {
   return err;
 }
 
-// Winograd F(2x2,3x3) form of conv3x3 (wino.hip): V = B^T d B, 16 GEMMs M_f = V_f U_f on the implicit-GEMM kernel (the 16
-// frequencies x Bp items are its "batch", weights selected per frequency), out = A^T M A + bias with the GroupNorm sums.
-hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats,
-                        const WinoGnArgs* gn = nullptr) {
+// Winograd F(2x2,3x3) convolution (wino.hip): V = B^T d B, 16 GEMMs M_f = V_f U_f on the implicit-GEMM kernel, out = A^T M A
+// (+ bias, GroupNorm sums; + add, * frame mask for data gradients).  U: 16 matrices [K/bk][N][bk], K input and N output channels.
+struct WinoEpi {
+  const float* bias = nullptr;
+  double* stats = nullptr;
+  const float* add = nullptr; int add_ld = 0;
+  bool mask_out = false;
+};
+hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int K, int N, int bk, int level, float* out, int out_ld,
+                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   Buffers& b = *e.b;
-  hipError_t err = launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, w.cin, gn, e.s);
+  hipError_t err = launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, gn, e.s);
   if (err != hipSuccess) return err;
   ConvArgs a;
   memset(&a, 0, sizeof a);
-  a.in = b.wino_v; a.in_ld = w.cin;
-  a.wt = w.w->wino.p; a.wt_bstride = (long long)w.cout * w.cin;
-  a.Hin = th; a.Win = tw; a.Cin = w.cin; a.Cout = w.cout;
+  a.in = b.wino_v; a.in_ld = K;
+  a.wt = U; a.wt_bstride = (long long)N * K;
+  a.Hin = th; a.Win = tw; a.Cin = K; a.Cout = N;
   a.Hs = th; a.Ws = tw; a.istride = 1;
-  a.bk = w.w->bk;
+  a.bk = bk;
   a.omask_bmod = 1;
   a.zeros = e.h->zeros;
   a.ntaps = 1;
@@ -425,18 +435,20 @@ hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, 
   // Output transform inside the GEMM kernel (one workgroup walks the 16 frequencies of its tile) when that still leaves
   // enough workgroups for the chip; otherwise 16x more, shorter workgroups and a separate transform pass.  Both forms add in
   // the same order, so the choice (which depends on the batch) does not change a single bit of the result.
-  const long long fused_wgs = (long long)((th * tw + 63) / 64) * ((w.cout + 127) / 128) * e.Bp;
+  const long long fused_wgs = (long long)((th * tw + 63) / 64) * ((N + 127) / 128) * e.Bp;
   if (fused_wgs >= e.h->wino_fuse_min_wgs) {
     a.wino_out = 1;
     a.B = e.Bp; a.Hout = H; a.Wout = W; a.ostep = 2;
     a.out = out; a.out_ld = out_ld;
-    a.bias = w.b ? w.b->buf.p : nullptr;
-    a.stats = stats;
+    a.bias = ep.bias;
+    a.stats = ep.stats;
+    a.add = ep.add; a.add_ld = ep.add_ld;
+    if (ep.mask_out) set_omask(e, a, level);
     us_decoder* h = e.h;
     if (!h->prof_active) return launch_conv_igemm(a, e.s);
     us_decoder::ProfRec r;
     r.a = h->prof_event(); r.b = h->prof_event(); r.kind = 0;
-    r.flops = 2.0 * 16 * e.Bp * (double)th * tw * w.cout * (double)w.cin;
+    r.flops = 2.0 * 16 * e.Bp * (double)th * tw * N * (double)K;
     (void)hipEventRecord(r.a, e.s);
     err = launch_conv_igemm(a, e.s);
     (void)hipEventRecord(r.b, e.s);
@@ -444,11 +456,22 @@ hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, 
     return err;
   }
   a.wt_bdiv = e.Bp;
-  a.out = b.wino_m; a.out_ld = w.cout;
+  a.out = b.wino_m; a.out_ld = N;
   a.B = 16 * e.Bp; a.Hout = th; a.Wout = tw; a.ostep = 1;
   err = run_conv(e, a);
   if (err != hipSuccess) return err;
-  return launch_wino_output(b.wino_m, w.b ? w.b->buf.p : nullptr, out, out_ld, stats, e.Bp, H, W, w.cout, e.s);
+  WinoOutExtra x{};
+  x.add = ep.add; x.add_ld = ep.add_ld;
+  if (ep.mask_out) { x.mask = e.mask; x.mask_ld = e.T; x.mask_step = 1 << level; x.mask_bmod = e.Bm; }
+  return launch_wino_output(b.wino_m, ep.bias, out, out_ld, ep.stats, e.Bp, H, W, N, e.s, &x);
+}
+
+hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats,
+                        const WinoGnArgs* gn = nullptr) {
+  WinoEpi ep;
+  ep.bias = w.b ? w.b->buf.p : nullptr;
+  ep.stats = stats;
+  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn);
 }
 
 hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
@@ -805,12 +828,13 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
       ok = hipMalloc(reinterpret_cast<void**>(&s->dg.p), s->dg.n * sizeof(float)) == hipSuccess;
     }
     if (ok && s->want_wino) {
-      s->wino.n = (size_t)16 * s->shape[0] * s->shape[1];
-      ok = hipMalloc(reinterpret_cast<void**>(&s->wino.p), s->wino.n * sizeof(float)) == hipSuccess;
+      s->wino.n = s->wino_dg.n = (size_t)16 * s->shape[0] * s->shape[1];
+      ok = hipMalloc(reinterpret_cast<void**>(&s->wino.p), s->wino.n * sizeof(float)) == hipSuccess &&
+           hipMalloc(reinterpret_cast<void**>(&s->wino_dg.p), s->wino_dg.n * sizeof(float)) == hipSuccess;
     }
     if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); }
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); }
       return US_EHIP;
     }
   }
@@ -820,7 +844,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); }
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
@@ -860,7 +884,8 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
       // wino.p is set; every workspace plan of this handle then has the V/M scratch)
       if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
-      US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
+      if (s->wino_dg.p) US_HIP(h, launch_wino_pack_weight(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], s->bk_dg, st, true));
+      else US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
       break;
     case Kind::CONVT_IOHW:
       US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));

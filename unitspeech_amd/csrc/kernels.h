@@ -39,6 +39,8 @@ struct ConvArgs {
   int tm;                // rows per workgroup: 128, 64 or 0 = choose from the grid size
   int ksplit;            // set by the launcher: K slices per tile (1 = single pass)
   int wino_out;          // 1: `in` = V [16][B][Hs][Ws][Cin], `wt` = 16 matrices wt_bstride apart; Winograd output transform in the kernel
+  int splitk_by_batch;   // 1: the split-K slice count may depend on the batch (training); 0: per-item geometry only, so that an
+                         // utterance's result never depends on what it is batched with (sampling)
   float* splitk_ws;      // optional scratch for split-K partial slabs (splitk_ws_floats floats); null disables split-K
   long long splitk_ws_floats;
   int debug;             // timing ablations for tools/conv_bench (0 in production): 1 = no DMA after the prologue,
@@ -201,7 +203,8 @@ hipError_t launch_mul_mish_grad(float* g, int g_ld, const float* x, int x_ld, in
 // 4x-expanded intermediate tensors, which pays where activations are small next to the weights (levels >= 1).
 namespace us {
 // U[f][Cout][Cin] = (G g G^T)[f], packed per frequency like a 1x1 conv: dst[f][Cin/bk][Cout][bk]; src Conv2d OIHW 3x3
-hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s);
+// dgrad = true: the transform of the 180-degree-rotated, channel-swapped filter (data gradient), dst[16][Cout/bk][Cin][bk]
+hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s, bool dgrad = false);
 // x: [B][H][W][x_ld] (C channels) -> V: [16][B][th][tw][C], th = ceil(H/2), tw = ceil(W/2); zero padding outside the image.
 // gn != null: x is a raw conv output and d = (mish(GroupNorm(x)) * mask + temb) * mask is transformed instead (the
 // block-1 gn_apply of a ResnetBlock fused into the input transform of its second convolution)
@@ -212,6 +215,11 @@ struct WinoGnArgs {
 };
 hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, const WinoGnArgs* gn, hipStream_t s);
 // M: [16][B][th][tw][C] -> out[B][H][W][out_ld] = A^T M A + bias; optional GroupNorm partial sums [B][8][2] of the result
+// optional epilogue of the separate output transform: out = (Y + bias + add) * mask  (data gradients: residual sum + frame mask)
+struct WinoOutExtra {
+  const float* add; int add_ld;                          // pixel-indexed like out
+  const float* mask; int mask_ld, mask_step, mask_bmod;  // column ox reads mask[ox * mask_step]
+};
 hipError_t launch_wino_output(const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
-                              hipStream_t s);
+                              hipStream_t s, const WinoOutExtra* extra = nullptr);
 }  // namespace us

@@ -334,10 +334,13 @@ __device__ __forceinline__ GnStat gn_stat(const double* st, double cnt) {
   return r;
 }
 
+// A thread owns one channel quad for its whole life (C/4 divides 256 or is a multiple of it for every width of the U-Net; any
+// other width takes the re-derive-per-element branch), reads 16 bytes per operand and keeps its per-channel and per-group sums
+// in registers: one round of LDS atomics per thread at the end instead of two per element.
 template <int PASS>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   const int b = blockIdx.y;
-  const int C = a.C, cg = C / kGroups;
+  const int C = a.C, cg = C / kGroups, C4 = C >> 2;
   const long long n = (long long)a.H * a.W;
   const double cnt = (double)n * cg;
   __shared__ float s_mean[kGroups], s_rstd[kGroups], s_s1[kGroups], s_s2[kGroups];
@@ -361,60 +364,100 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   const float* gb = a.g + (long long)b * n * a.g_ld;
   float* ob = PASS == 2 ? a.gy + (long long)b * n * a.gy_ld : nullptr;
   const float* mb = a.mask + (long long)(b % a.mask_bmod) * a.mask_ld;
-  const long long total = n * C;
-  double g1[kGroups], g2[kGroups];
+  const long long total = n * C4;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = blockIdx.x * 256LL + threadIdx.x;
+  const bool fixed_quad = (stride % C4) == 0;
+  int c = (int)(i % C4) * 4;
+  f32x4 ga, be, mean4, rstd4, s14, s24;
+  f32x4 ch0 = {0.f, 0.f, 0.f, 0.f}, ch1 = {0.f, 0.f, 0.f, 0.f};    // PASS 1: (sum dz*xn, sum dz); PASS 2: (sum gy, -)
+  double g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
+  int cur = -1;
+  auto flush = [&]() {
+    if (cur < 0) return;
 #pragma unroll
-  for (int k = 0; k < kGroups; ++k) g1[k] = g2[k] = 0.0;
-  // element order: channel fastest; a thread keeps the same channel when 256 % C == 0 or C % 256 == 0 (always true here)
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long long p = i / C;
-    const float m = mb[(int)(p % a.W) * a.mask_step];
-    const int gi = c / cg;
-    const float xn = (yb[p * a.y_ld + c] - s_mean[gi]) * s_rstd[gi];
-    const float ga = a.gamma[c];
-    const float z = xn * ga + a.beta[c];
-    const float dz = gb[p * a.g_ld + c] * m * mish_grad(z);
-    if (PASS == 1) {
-      atomicAdd(&s_ch[0][c], dz * xn);
-      atomicAdd(&s_ch[1][c], dz);
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&s_ch[0][cur + k], ch0[k]);
+      if (PASS == 1) {
+        atomicAdd(&s_ch[1][cur + k], ch1[k]);
+        atomicAdd(&s_grp[(cur + k) / cg][0], g1[k]);
+        atomicAdd(&s_grp[(cur + k) / cg][1], g2[k]);
+        g1[k] = g2[k] = 0.0;
+      }
+      ch0[k] = ch1[k] = 0.f;
+    }
+  };
+  auto load_quad = [&](int cc) {
+    flush();
+    cur = cc;
+    ga = *reinterpret_cast<const f32x4*>(a.gamma + cc);
+    be = *reinterpret_cast<const f32x4*>(a.beta + cc);
 #pragma unroll
-      for (int k = 0; k < kGroups; ++k)
-        if (k == gi) { g1[k] += (double)(dz * ga); g2[k] += (double)(dz * ga * xn); }
-    } else {
-      const float gy = s_rstd[gi] * (dz * ga - s_s1[gi] - xn * s_s2[gi]);
-      ob[p * a.gy_ld + c] = gy;
-      atomicAdd(&s_ch[0][c], gy);
+    for (int k = 0; k < 4; ++k) {
+      const int gk = (cc + k) / cg;
+      mean4[k] = s_mean[gk];
+      rstd4[k] = s_rstd[gk];
+      if (PASS == 2) { s14[k] = s_s1[gk]; s24[k] = s_s2[gk]; }
+    }
+  };
+  if (i < total) load_quad(c);
+  long long p = i / C4;
+  int w = (int)(p % a.W);
+  const long long rpi = stride / C4;
+  const int wstep = (int)(rpi % a.W);
+  for (; i < total; i += stride) {
+    if (!fixed_quad) {
+      p = i / C4;
+      w = (int)(p % a.W);
+      c = (int)(i - p * C4) * 4;
+      if (c != cur) load_quad(c);
+    }
+    const float m = mb[w * a.mask_step];
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(yb + p * a.y_ld + c);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + p * a.g_ld + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xn = (yv[k] - mean4[k]) * rstd4[k];
+      const float z = xn * ga[k] + be[k];
+      const float dz = gv[k] * m * mish_grad(z);
+      if (PASS == 1) {
+        ch0[k] += dz * xn;
+        ch1[k] += dz;
+        g1[k] += (double)(dz * ga[k]);
+        g2[k] += (double)(dz * ga[k] * xn);
+      } else {
+        o[k] = rstd4[k] * (dz * ga[k] - s14[k] - xn * s24[k]);
+        ch0[k] += o[k];
+      }
+    }
+    if (PASS == 2) *reinterpret_cast<f32x4*>(ob + p * a.gy_ld + c) = o;
+    if (fixed_quad) {
+      p += rpi;
+      w += wstep;
+      if (w >= a.W) w -= a.W;
     }
   }
-  if (PASS == 1) {
-#pragma unroll
-    for (int k = 0; k < kGroups; ++k) {
-      double v1 = g1[k], v2 = g2[k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) { v1 += __shfl_xor(v1, off); v2 += __shfl_xor(v2, off); }
-      if ((threadIdx.x & 63) == 0) { atomicAdd(&s_grp[k][0], v1); atomicAdd(&s_grp[k][1], v2); }
-    }
-  }
+  flush();
   __syncthreads();
   if (PASS == 1) {
-    for (int i = threadIdx.x; i < C; i += 256) {
-      atomicAdd(&a.ggamma[i], s_ch[0][i]);
-      atomicAdd(&a.gbeta[i], s_ch[1][i]);
+    for (int k = threadIdx.x; k < C; k += 256) {
+      atomicAdd(&a.ggamma[k], s_ch[0][k]);
+      atomicAdd(&a.gbeta[k], s_ch[1][k]);
     }
     if (threadIdx.x < kGroups * 2)
       atomicAdd(&a.gsum[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], s_grp[threadIdx.x >> 1][threadIdx.x & 1]);
   } else if (a.gbias) {
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&a.gbias[i], s_ch[0][i]);
+    for (int k = threadIdx.x; k < C; k += 256) atomicAdd(&a.gbias[k], s_ch[0][k]);
   }
 }
 
 hipError_t launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
-  if (a.C > 1024 || a.C % kGroups != 0) return hipErrorInvalidValue;
-  long long total = (long long)a.H * a.W * a.C;
-  int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
+  if (a.C > 1024 || a.C % kGroups != 0 || a.C % 4 != 0 || a.y_ld % 4 != 0 || a.g_ld % 4 != 0 || a.gy_ld % 4 != 0) return hipErrorInvalidValue;
+  long long total = (long long)a.H * a.W * (a.C / 4);
+  int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
   if (blocks < 1) blocks = 1;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(gn_bwd_kernel<1>, dim3(blocks, a.B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(gn_bwd_kernel<2>, dim3(blocks, a.B), dim3(256), 0, s, a);
   return hipGetLastError();

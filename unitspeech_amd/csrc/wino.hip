@@ -122,7 +122,7 @@ hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, i
 }
 
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ out,
-                                                          int out_ld, double* __restrict__ stats, int B, int H, int W, int C) {
+                                                          int out_ld, double* __restrict__ stats, int B, int H, int W, int C, WinoOutExtra x) {
   __shared__ double s_g[kGroups][2];
   const int C4 = C >> 2;
   const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
@@ -185,13 +185,18 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       for (int q = 0; q < 2; ++q) y[r][q] += bv;
     if (stats && tc != c) { flush(); tc = c; }
     float* ob = out + (long long)b * H * W * out_ld + c;
+    const float* ab = x.add ? x.add + (long long)b * H * W * x.add_ld + c : nullptr;
+    const float* mk = x.mask ? x.mask + (long long)(b % x.mask_bmod) * x.mask_ld : nullptr;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int oy = 2 * ty + r, ox = 2 * tx + q;
         if (oy < H && ox < W) {
-          *reinterpret_cast<f32x4*>(ob + ((long long)oy * W + ox) * out_ld) = y[r][q];
+          f32x4 v = y[r][q];                   // statistics (forward only) are of the plain conv output
+          if (ab) v += *reinterpret_cast<const f32x4*>(ab + ((long long)oy * W + ox) * x.add_ld);
+          if (mk) v *= mk[ox * x.mask_step];
+          *reinterpret_cast<f32x4*>(ob + ((long long)oy * W + ox) * out_ld) = v;
           if (stats) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { t1[k] += (double)y[r][q][k]; t2[k] += (double)(y[r][q][k] * y[r][q][k]); }
@@ -208,23 +213,31 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 }
 
 hipError_t launch_wino_output(const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
-                              hipStream_t s) {
-  if (C % 4 != 0 || out_ld % 4 != 0 || C % kGroups != 0) return hipErrorInvalidValue;
+                              hipStream_t s, const WinoOutExtra* extra) {
+  if (C % 4 != 0 || out_ld % 4 != 0 || C % kGroups != 0 || (extra && extra->add && extra->add_ld % 4 != 0)) return hipErrorInvalidValue;
+  WinoOutExtra x{};
+  if (extra) x = *extra;
+  if (x.mask_bmod < 1) x.mask_bmod = 1;
   const long long per_item = (long long)((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   int blocks = (int)((per_item + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wino_output_kernel, dim3(blocks, B), dim3(256), 0, s, M, bias, out, out_ld, stats, B, H, W, C);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(blocks, B), dim3(256), 0, s, M, bias, out, out_ld, stats, B, H, W, C, x);
   return hipGetLastError();
 }
 
-// U = G g G^T per (co, ci); dst[f][ci/bk][co][bk]
-__global__ void wino_pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int bk) {
+// U = G g G^T per (co, ci); forward: dst[f][ci/bk][co][bk].  dgrad: the data gradient of a 3x3 / stride 1 / pad 1 conv is the
+// conv of the output gradient with the filter rotated by 180 degrees and the channel roles swapped, so
+// g'[ky][kx] = g[2-ky][2-kx], GEMM-K = co, GEMM-N = ci: dst[f][co/bk][ci][bk]
+__global__ void wino_pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int bk, int dgrad) {
   const long long total = (long long)Cout * Cin;
-  const int nchunk = Cin / bk;
+  const int nchunk = (dgrad ? Cout : Cin) / bk;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin), co = (int)(i / Cin);
-    const float* g = src + i * 9;
+    const float* gs = src + i * 9;
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = dgrad ? gs[8 - k] : gs[k];
     float gg[4][3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -233,8 +246,8 @@ __global__ void wino_pack_weight_kernel(const float* __restrict__ src, float* __
       gg[2][q] = 0.5f * (g[q] - g[3 + q] + g[6 + q]);
       gg[3][q] = g[6 + q];
     }
-    const long long base = ((long long)(ci / bk) * Cout + co) * bk + ci % bk;
-    const long long fstride = (long long)nchunk * Cout * bk;
+    const long long base = dgrad ? ((long long)(co / bk) * Cin + ci) * bk + co % bk : ((long long)(ci / bk) * Cout + co) * bk + ci % bk;
+    const long long fstride = (long long)nchunk * (dgrad ? Cin : Cout) * bk;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float u0 = gg[r][0], u1 = 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]), u2 = 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]), u3 = gg[r][2];
@@ -246,12 +259,12 @@ __global__ void wino_pack_weight_kernel(const float* __restrict__ src, float* __
   }
 }
 
-hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s) {
-  if (Cin % bk != 0) return hipErrorInvalidValue;
+hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s, bool dgrad) {
+  if ((dgrad ? Cout : Cin) % bk != 0) return hipErrorInvalidValue;
   long long total = (long long)Cout * Cin;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, bk);
+  hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, bk, dgrad ? 1 : 0);
   return hipGetLastError();
 }
 
