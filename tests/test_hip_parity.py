@@ -316,7 +316,12 @@ def test_fine_tune_step_matches_oracle_and_updates_weights(golden, fused):
         gr, pr = torch.from_numpy(np.asarray(a[f"grad_{i}"])), torch.from_numpy(np.asarray(a[f"param_{i}"]))
         assert (params[k].grad.cpu() - gr).abs().max() <= 2e-4 * gr.abs().max() + 1e-9, k      # clipped in place
         d_ref, d_got = pr - start[k].cpu(), params[k].detach().cpu() - start[k].cpu()
-        assert (d_got - d_ref).abs().max() <= 4e-7, k              # the first Adam step moves every element by ~lr = 2e-5
+        # The first Adam step moves an element by lr * g / (|g| + eps): ~lr = 2e-5 wherever |g| >> eps = 1e-8, but an element whose
+        # gradient is itself ~eps turns an absolute gradient error of 1e-9 (fp32 atomics order) into a few % of lr.
+        err = (d_got - d_ref).abs()
+        solid = gr.abs() > 1e-6
+        assert err[solid].max() <= 2e-7 if solid.any() else True, k
+        assert err.max() <= 2e-6, k
     with torch.no_grad():          # the engine must pick the new weights up
         x = torch.zeros(1, 80, 16, device=DEV)
         out = model.estimator(x, torch.ones(1, 1, 16, device=DEV), x, torch.full((1,), 0.5, device=DEV), g["spk_emb"].to(DEV))

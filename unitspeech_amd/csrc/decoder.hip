@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <string>
@@ -287,7 +288,7 @@ struct Buffers {
   bool tproj_ready = false;        // true when tproj already holds this evaluation's time projections
 };
 
-void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
+void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false) {
   const int L = h->cfg.n_mults, F = h->cfg.n_feats;
   const size_t B = (size_t)Bp;
   b.in2 = A.alloc<float>(B * F * T * 2);
@@ -333,16 +334,22 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b) {
   b.splitk_floats = B * ((size_t)4 << 20);  // 4 Mi floats per item: the conv launcher's bound on its split-K slabs
   b.splitk = A.alloc<float>(b.splitk_floats);
   b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
-  // Winograd scratch: the widest input (2*C[l] channels into ups.r1) and output over the Winograd levels
+  // Winograd scratch, sized from the convolutions that use it: V holds the conv's input channels and M its output channels;
+  // the data gradient (training plans) swaps the two
   size_t wv = 0, wm = 0;
-  for (int l = h->wino_min_level; l < L; ++l) {
-    size_t tiles = (size_t)(((F >> l) + 1) / 2) * (((T >> l) + 1) / 2);
-    size_t cin = 2 * (size_t)h->C[l], cout = h->C[l];
-    if (l > 0 && (size_t)h->C[l - 1] > cin) cin = h->C[l - 1];
-    if (16 * B * tiles * cin > wv) wv = 16 * B * tiles * cin;
-    if (16 * B * tiles * cin > wm) wm = 16 * B * tiles * cin;      // the data gradient's product tensor has the conv's Cin channels
-    (void)cout;
-  }
+  auto need = [&](const ConvW& c, int l) {
+    if (!c.w || !c.w->want_wino) return;
+    const size_t tiles = (size_t)(((F >> l) + 1) / 2) * (((T >> l) + 1) / 2);
+    const size_t kin = train ? (size_t)std::max(c.cin, c.cout) : (size_t)c.cin;
+    const size_t kout = train ? (size_t)std::max(c.cin, c.cout) : (size_t)c.cout;
+    wv = std::max(wv, 16 * B * tiles * kin);
+    wm = std::max(wm, 16 * B * tiles * kout);
+  };
+  auto need_r = [&](const ResnetW& r) { need(r.c1, r.level); need(r.c2, r.level); };
+  for (auto& d : h->downs) { need_r(d.r1); need_r(d.r2); }
+  need_r(h->mid1); need_r(h->mid2);
+  for (auto& u : h->ups) { need_r(u.r1); need_r(u.r2); }
+  need(h->final_conv3, 0);
   if (wv) { b.wino_v = A.alloc<float>(wv); b.wino_m = A.alloc<float>(wm); }
 }
 
