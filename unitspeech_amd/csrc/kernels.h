@@ -205,15 +205,8 @@ namespace us {
 // U[f][Cout][Cin] = (G g G^T)[f], packed per frequency like a 1x1 conv: dst[f][Cin/bk][Cout][bk]; src Conv2d OIHW 3x3
 // dgrad = true: the transform of the 180-degree-rotated, channel-swapped filter (data gradient), dst[16][Cout/bk][Cin][bk]
 hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s, bool dgrad = false);
-// x: [B][H][W][x_ld] (C channels) -> V: [16][B][th][tw][C], th = ceil(H/2), tw = ceil(W/2); zero padding outside the image.
-// gn != null: x is a raw conv output and d = (mish(GroupNorm(x)) * mask + temb) * mask is transformed instead (the
-// block-1 gn_apply of a ResnetBlock fused into the input transform of its second convolution)
-struct WinoGnArgs {
-  const double* stats;                 // [B][8][2] sums of x
-  const float *gamma, *beta, *temb;    // temb: [B][C] or null
-  const float* mask; int mask_ld, mask_step, mask_bmod;
-};
-hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, const WinoGnArgs* gn, hipStream_t s);
+// x: [B][H][W][x_ld] (C channels) -> V: [16][B][th][tw][C], th = ceil(H/2), tw = ceil(W/2); zero padding outside the image
+hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s);
 // M: [16][B][th][tw][C] -> out[B][H][W][out_ld] = A^T M A + bias; optional GroupNorm partial sums [B][8][2] of the result
 // optional epilogue of the separate output transform: out = (Y + bias + add) * mask  (data gradients: residual sum + frame mask)
 struct WinoOutExtra {

@@ -10,80 +10,29 @@ namespace us {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// d = mish(gn(y)) * mask + temb, masked again: gn_apply_kernel's block-1 form (ops.hip), evaluated on the fly
-__device__ __forceinline__ float wino_mish(float x) {
-  if (x > 20.f) return x;
-  const float w = __expf(x);
-  const float u = w * (w + 2.f);
-  return x * (u * __frcp_rn(u + 2.f));
-}
-
-// one thread = one (tile, channel quad); grid (blocks, B).  GN = true: the source is a raw conv output and the thread
-// applies GroupNorm + Mish + mask + time embedding to each of its 16 pixels first (every pixel sits in 4 tiles, so this
-// costs 4x the transcendental work of a separate pass and saves that pass's write and re-read).
-template <bool GN>
+// one thread = one (tile, channel quad); grid (blocks, B)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ V, int B, int H, int W,
-                                                         int C, WinoGnArgs g) {
-  __shared__ float s_mean[kGroups], s_rstd[kGroups];
+                                                         int C) {
   const int C4 = C >> 2;
   const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
   const int b = blockIdx.y;
   const long long per_item = (long long)th * tw * C4;
   const long long plane = (long long)B * th * tw * C;          // floats per frequency
-  const int cg = C / kGroups;
-  if (GN) {
-    if (threadIdx.x < kGroups) {
-      const double cnt = (double)H * W * cg;
-      const double* st = g.stats + ((long long)b * kGroups + threadIdx.x) * 2;
-      double mean = st[0] / cnt;
-      double var = st[1] / cnt - mean * mean;
-      if (var < 0) var = 0;
-      s_mean[threadIdx.x] = (float)mean;
-      s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
-    }
-    __syncthreads();
-  }
   const float* xb = x + (long long)b * H * W * x_ld;
-  const float* mb = GN ? g.mask + (long long)(b % g.mask_bmod) * g.mask_ld : nullptr;
-  int cur_c = -1;
-  f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, te = sc;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per_item; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4;
     long long t = i / C4;
     const int tx = (int)(t % tw);
     const int ty = (int)(t / tw);
-    if (GN && c != cur_c) {
-      cur_c = c;
-      f32x4 ga = *reinterpret_cast<const f32x4*>(g.gamma + c);
-      f32x4 be = *reinterpret_cast<const f32x4*>(g.beta + c);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int gk = (c + k) / cg;
-        sc[k] = s_rstd[gk] * ga[k];
-        sh[k] = be[k] - s_mean[gk] * sc[k];
-      }
-      if (g.temb) te = *reinterpret_cast<const f32x4*>(g.temb + (long long)b * C + c);
-    }
     f32x4 d[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ix = 2 * tx - 1 + q;
-      const bool okx = (unsigned)ix < (unsigned)W;
-      float m = 0.f;
-      if (GN && okx) m = mb[ix * g.mask_step];
+    for (int r = 0; r < 4; ++r) {
+      const int iy = 2 * ty - 1 + r;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int iy = 2 * ty - 1 + r;
-        const bool ok = okx && (unsigned)iy < (unsigned)H;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          v = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld + c);
-          if (GN) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (wino_mish(v[k] * sc[k] + sh[k]) * m + te[k]) * m;
-          }
-        }
-        d[r][q] = v;
+      for (int q = 0; q < 4; ++q) {
+        const int ix = 2 * tx - 1 + q;
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        d[r][q] = ok ? *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     // rows: t = B^T d
@@ -108,16 +57,13 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
-hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, const WinoGnArgs* gn, hipStream_t s) {
-  if (C % 4 != 0 || x_ld % 4 != 0 || C % kGroups != 0) return hipErrorInvalidValue;
+hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s) {
+  if (C % 4 != 0 || x_ld % 4 != 0) return hipErrorInvalidValue;
   const long long per_item = (long long)((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   int blocks = (int)((per_item + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  if (gn)
-    hipLaunchKernelGGL(wino_input_kernel<true>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C, *gn);
-  else
-    hipLaunchKernelGGL(wino_input_kernel<false>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C, WinoGnArgs{});
+  hipLaunchKernelGGL(wino_input_kernel, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C);
   return hipGetLastError();
 }
 
