@@ -63,8 +63,7 @@ for u in range(L - 1):
     resnet(f"ups.{u}.r1", l, 2 * C[l], co)
     resnet(f"ups.{u}.r2", l, co, co)
     attn(f"ups.{u}.attn", l, co)
-    for ph in range(4):
-        conv(f"ups.{u}.up phase{ph} {co} L{l}->L{l-1}", npx(l), co, co, 4)
+    conv(f"ups.{u}.up 4x4s2T {co} L{l}->L{l-1} (4 phases, one launch)", npx(l), co, co, 16)
 conv("final 3x3 128->128 L0", npx(0), C[0], C[0], 9, wino=True)
 
 rows = [r for r in csv.DictReader(open(a.trace)) if "conv_igemm" in r["Kernel_Name"]]

@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z;
+  const int phase = a.nphase > 1 ? (int)(blockIdx.z % a.nphase) : 0;
+  const int b = a.nphase > 1 ? (int)(blockIdx.z / a.nphase) : (int)blockIdx.z;
+  const unsigned long long dy_bits = a.nphase > 1 ? a.ph_dy[phase] : a.dy_bits, dx_bits = a.nphase > 1 ? a.ph_dx[phase] : a.dx_bits,
+                           wtap_bits = a.nphase > 1 ? a.ph_wtap[phase] : a.wtap_bits;
+  const int a_oy0 = a.nphase > 1 ? (phase >> 1) : a.oy0, a_ox0 = a.nphase > 1 ? (phase & 1) : a.ox0;
   // split-K: blockIdx.x = m_tile * ksplit + ks; slice ks sums the chunks [s_lo, s_lo + S) of the ntaps * nchunk total
   const int ks = a.ksplit > 1 ? (int)(blockIdx.x % a.ksplit) : 0;
   const int m0 = (a.ksplit > 1 ? (int)(blockIdx.x / a.ksplit) : (int)blockIdx.x) * TM, n0 = blockIdx.y * TN;
@@ -105,9 +109,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   unsigned aoff[IA];    // per-lane byte offset of the current tap's source row chunk (>= a_bytes: reads zeros)
   unsigned wtap_bytes = 0;
   auto setup_tap = [&](int tap) {
-    const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
-    const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
-    const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);
+    const int dy = (int)((dy_bits >> (4 * tap)) & 15) - 8;
+    const int dx = (int)((dx_bits >> (4 * tap)) & 15) - 8;
+    const int wt_i = (int)((wtap_bits >> (4 * tap)) & 15);
 #pragma unroll
     for (int j = 0; j < IA; ++j) {
       const int iy = my[j] * a.istride + dy, ix = mx[j] * a.istride + dx;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
-  const bool dense = (a.ostep == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Hs == a.Hout && a.Ws == a.Wout);
+  const bool dense = (a.ostep == 1 && a_oy0 == 0 && a_ox0 == 0 && a.Hs == a.Hout && a.Ws == a.Wout);
   const float alpha = a.alpha ? *a.alpha : 1.f;
   float* out_b = a.out + (long long)b * a.Hout * a.Wout * a.out_ld;
   const float* add_b = a.add ? a.add + (long long)b * a.Hout * a.Wout * a.add_ld : nullptr;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int yi = 0; yi < NY; ++yi) {
   const f32x16 (&A)[MB][2] = WINO ? Y[yi] : acc;
-  const int oy0 = WINO ? (yi >> 1) : a.oy0, ox0 = WINO ? (yi & 1) : a.ox0;
+  const int oy0 = WINO ? (yi >> 1) : a_oy0, ox0 = WINO ? (yi & 1) : a_ox0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m_base = m0 + wm * WM + mb * 32;
@@ -590,6 +594,10 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     tm = 64;
     a.splitk_ws = nullptr;
   }
+  if (a.nphase > 1) {
+    if (a.nphase != 4 || a.ostep != 2 || a.wino_out) return hipErrorInvalidValue;
+    a.splitk_ws = nullptr;            // the merged grid is 4x larger already; slabs are per (item, single phase)
+  }
   if (tm == 0) {
     const long long wgs128 = (long long)((Ms + 127) / 128) * nt * a.B;
     tm = wgs128 < g_tm64_threshold ? 64 : 128;
@@ -614,7 +622,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (k > 32) k = 32;
     if (k >= 2 && k * (long long)a.B * Ms * a.Cout <= a.splitk_ws_floats) a.ksplit = (int)k;
   }
-  dim3 grid(mt * a.ksplit, nt, a.B);
+  dim3 grid(mt * a.ksplit, nt, a.B * (a.nphase > 1 ? a.nphase : 1));
   const size_t lds = lds_bytes(a.bk, tm);
   if (a.wino_out) {
     if (a.bk == 32)

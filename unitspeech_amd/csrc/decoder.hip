@@ -404,7 +404,7 @@ hipError_t run_conv(EvalCtx& e, const ConvArgs& a) {
   r.a = h->prof_event();
   r.b = h->prof_event();
   r.kind = 0;
-  r.flops = 2.0 * a.B * (double)a.Hs * a.Ws * a.Cout * (double)a.Cin * a.ntaps;
+  r.flops = 2.0 * a.B * (double)a.Hs * a.Ws * a.Cout * (double)a.Cin * a.ntaps * (a.nphase > 1 ? a.nphase : 1);
   (void)hipEventRecord(r.a, e.s);
   hipError_t err = launch_conv_igemm(a, e.s);
   (void)hipEventRecord(r.b, e.s);
@@ -520,18 +520,17 @@ hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   static const int KY[2][2] = {{1, 3}, {2, 0}};
   static const int DY[2][2] = {{0, -1}, {0, 1}};
+  // all four output phases in one launch (ConvArgs::nphase)
+  ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, 2 * H, 2 * W);
+  a.Hs = H; a.Ws = W; a.ostep = 2;
+  a.ntaps = 4;
+  a.nphase = 4;
   for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
-      ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, 2 * H, 2 * W);
-      a.Hs = H; a.Ws = W; a.ostep = 2; a.oy0 = py; a.ox0 = px;
-      a.ntaps = 4;
+    for (int px = 0; px < 2; ++px)
       for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j) a.set_tap(i * 2 + j, DY[py][i], DY[px][j], KY[py][i] * 4 + KY[px][j]);
-      set_omask(e, a, level - 1);   // the upsampled tensor is only consumed masked (next level's ResnetBlock / final Block)
-      hipError_t err = run_conv(e, a);
-      if (err != hipSuccess) return err;
-    }
-  return hipSuccess;
+        for (int j = 0; j < 2; ++j) a.set_phase_tap(py * 2 + px, i * 2 + j, DY[py][i], DY[px][j], KY[py][i] * 4 + KY[px][j]);
+  set_omask(e, a, level - 1);   // the upsampled tensor is only consumed masked (next level's ResnetBlock / final Block)
+  return run_conv(e, a);
 }
 
 hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* stats, const Slot* g, const Slot* bta,

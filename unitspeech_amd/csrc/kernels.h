@@ -51,6 +51,16 @@ struct ConvArgs {
     dx_bits |= (unsigned long long)(dx + 8) << (4 * i);
     wtap_bits |= (unsigned long long)wtap << (4 * i);
   }
+  // nphase = 4: the four output phases (oy0, ox0) = (ph >> 1, ph & 1) of a stride-2 transposed convolution in ONE launch
+  // (grid z = B * 4), each with its own tap table; oy0 / ox0 / dy_bits / dx_bits / wtap_bits above are then unused.  One
+  // 4x larger grid instead of four sub-wave ones back to back.
+  int nphase;
+  unsigned long long ph_dy[4], ph_dx[4], ph_wtap[4];
+  void set_phase_tap(int ph, int i, int dy, int dx, int wtap) {
+    ph_dy[ph] |= (unsigned long long)(dy + 8) << (4 * i);
+    ph_dx[ph] |= (unsigned long long)(dx + 8) << (4 * i);
+    ph_wtap[ph] |= (unsigned long long)wtap << (4 * i);
+  }
 };
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 hipError_t conv_igemm_init();   // one-time function attributes (dynamic LDS size)
