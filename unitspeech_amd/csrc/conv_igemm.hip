@@ -568,6 +568,7 @@ static int g_splitk = -1;
 hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
+  if (!a.in || !a.wt || !a.out) return hipErrorInvalidValue;
   if ((a.bk != 16 && a.bk != 32) || a.Cin % a.bk != 0 || a.ntaps < 1 || a.ntaps > kMaxTaps) return hipErrorInvalidValue;
   if (a.in_ld % 4 != 0) return hipErrorInvalidValue;   // 16-byte DMA pieces of the activation rows
   if (a.Cout % 4 != 0 || a.out_ld % 4 != 0 || (a.add && a.add_ld % 4 != 0)) return hipErrorInvalidValue;   // 16-byte epilogue

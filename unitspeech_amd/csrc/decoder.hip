@@ -816,11 +816,15 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
     }
   }
   for (auto& s : h->slots) {
-    s->buf.n = numel(s->shape);
-    bool ok = hipMalloc(reinterpret_cast<void**>(&s->buf.p), s->buf.n * sizeof(float)) == hipSuccess;
-    if (ok && (s->kind != Kind::RAW || s->dg_as_1x1)) {
-      s->dg.n = s->buf.n;
-      ok = hipMalloc(reinterpret_cast<void**>(&s->dg.p), s->dg.n * sizeof(float)) == hipSuccess;
+    // a conv that lives in the Winograd domain keeps only its two Winograd packs (forward, data gradient)
+    bool ok = true;
+    s->buf.n = numel(s->shape);      // element count of the tensor (also sizes gradient / scratch buffers), allocated or not
+    if (!s->want_wino) {
+      ok = hipMalloc(reinterpret_cast<void**>(&s->buf.p), s->buf.n * sizeof(float)) == hipSuccess;
+      if (ok && (s->kind != Kind::RAW || s->dg_as_1x1)) {
+        s->dg.n = s->buf.n;
+        ok = hipMalloc(reinterpret_cast<void**>(&s->dg.p), s->dg.n * sizeof(float)) == hipSuccess;
+      }
     }
     if (ok && s->want_wino) {
       s->wino.n = s->wino_dg.n = (size_t)16 * s->shape[0] * s->shape[1];
