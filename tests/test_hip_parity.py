@@ -120,7 +120,7 @@ def test_winograd_forms_agree_bitwise_and_match_direct_convolution(tiny):
     args = [inp[k].to(DEV) for k in ("z", "mask", "cond")] + [t.to(DEV), inp["spk_emb"].to(DEV)]
     outs = {}
     for name, env in (("fused", {"US_WINO_FUSE_MIN_WGS": 1}), ("separate", {"US_WINO_FUSE_MIN_WGS": 10 ** 9}),
-                      ("direct", {"US_WINO_MIN_LEVEL": 99}), ("default", {})):
+                      ("direct", {"US_WINO_MIN_LEVEL": 99}), ("gn_apart", {"US_WINO_FUSE_GN": 0}), ("default", {})):
         m = _model_with_env(TINY, **env)
         with torch.no_grad():
             outs[name] = m.estimator(*args).cpu()
@@ -130,6 +130,7 @@ def test_winograd_forms_agree_bitwise_and_match_direct_convolution(tiny):
     for name, o in outs.items():
         assert l1(o, ref) <= 2e-6, name
     assert l1(outs["direct"], outs["fused"]) <= 1e-6
+    assert l1(outs["gn_apart"], outs["default"]) <= 1e-6      # block1's GroupNorm+Mish inside / outside block2's input transform
 
 
 @pytest.mark.parametrize("w", ["11", "10", "01", "00"])

@@ -92,6 +92,7 @@ struct us_decoder {
   Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
   int n_resnets = 0;
   long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
+  bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
   int wino_min_level = 0;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
   std::shared_ptr<void> tape; // saved-activation record of the last us_estimator_forward_train call
@@ -421,11 +422,13 @@ struct WinoEpi {
   bool mask_out = false;
 };
 hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int K, int N, int bk, int level, float* out, int out_ld,
-                     const WinoEpi& ep) {
+                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   Buffers& b = *e.b;
-  hipError_t err = launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, e.s);
+  // gn: `in` is block1's raw conv output (ld == K); its GroupNorm + Mish + time embedding are evaluated inside the transform
+  hipError_t err = gn ? (in_ld == K ? launch_gn_wino_input(in, b.wino_v, e.Bp, H, W, K, *gn, e.s) : hipErrorInvalidValue)
+                      : launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, e.s);
   if (err != hipSuccess) return err;
   ConvArgs a;
   memset(&a, 0, sizeof a);
@@ -472,11 +475,12 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
   return launch_wino_output(b.wino_m, ep.bias, out, out_ld, ep.stats, e.Bp, H, W, N, e.s, &x);
 }
 
-hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
+hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats,
+                        const WinoGnArgs* gn = nullptr) {
   WinoEpi ep;
   ep.bias = w.b ? w.b->buf.p : nullptr;
   ep.stats = stats;
-  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep);
+  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn);
 }
 
 hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
@@ -567,9 +571,18 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
   double* st1 = next_stats(e);
   double* st2 = next_stats(e);
   CK(conv3x3(e, r.c1, in, in_ld, l, S1, r.cout, st1));
-  // block1 output + time embedding, pre-masked for block2's `x * mask` (:54)
-  CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, true, S1, r.cout));
-  CK(conv3x3(e, r.c2, S1, r.cout, l, S2, r.cout, st2));
+  if (r.c2.w->wino.p && b.wino_v && e.h->wino_fuse_gn && gn_wino_input_supported(r.cout)) {
+    // block1's GroupNorm + Mish + time embedding (pre-masked for block2's `x * mask`, :54) evaluated inside the Winograd input
+    // transform of block2's conv: h1 is never written
+    WinoGnArgs g;
+    g.stats = st1; g.gamma = r.g1->buf.p; g.beta = r.b1->buf.p; g.temb = tproj;
+    g.mask = e.mask; g.mask_ld = e.T; g.mask_step = 1 << l; g.mask_bmod = e.Bm;
+    CK(conv3x3_wino(e, r.c2, S1, r.cout, l, S2, r.cout, st2, &g));
+  } else {
+    // block1 output + time embedding, pre-masked for block2's `x * mask` (:54)
+    CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, true, S1, r.cout));
+    CK(conv3x3(e, r.c2, S1, r.cout, l, S2, r.cout, st2));
+  }
   if (r.has_res) {
     CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, nullptr, 0, false, false, out, out_ld));
     CK(conv1x1(e, r.res, in, in_ld, l, mask_out, out, out_ld, out, out_ld, nullptr, nullptr, 0, nullptr));
@@ -805,6 +818,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS")) h->wino_fuse_min_wgs = atoll(wf);
+  if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
   h->build();
   {
     int max_cin = 2 * h->C.back();

@@ -217,6 +217,15 @@ namespace us {
 hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s, bool dgrad = false);
 // x: [B][H][W][x_ld] (C channels) -> V: [16][B][th][tw][C], th = ceil(H/2), tw = ceil(W/2); zero padding outside the image
 hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s);
+// V of d = (mish(GroupNorm(y)) * mask + temb) * mask, y a raw conv output [B][H][W][C] (ld = C): block1's gn_apply of a
+// ResnetBlock folded into the input transform of its second convolution (C a multiple of 32)
+struct WinoGnArgs {
+  const double* stats;                 // [B][8][2] sums of y
+  const float *gamma, *beta, *temb;    // temb: [B][C] or null
+  const float* mask; int mask_ld, mask_step, mask_bmod;
+};
+bool gn_wino_input_supported(int C);
+hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s);
 // M: [16][B][th][tw][C] -> out[B][H][W][out_ld] = A^T M A + bias; optional GroupNorm partial sums [B][8][2] of the result
 // optional epilogue of the separate output transform: out = (Y + bias + add) * mask  (data gradients: residual sum + frame mask)
 struct WinoOutExtra {

@@ -67,6 +67,105 @@ hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, i
   return hipGetLastError();
 }
 
+// ---- block1's GroupNorm + Mish + time embedding evaluated straight into the Winograd domain ---------------------------------
+// V = B^T d B with d = (mish(GroupNorm(y)) * mask + temb) * mask (gn_apply_kernel's block-1 form, ops.hip) computed on the fly:
+// the activation h1 = d of a ResnetBlock (unitspeech.py:69-71) is never written.  A workgroup owns a block of 4 x 8 tiles and a
+// slab of 32 channels: it evaluates d once per pixel of the 10 x 18 patch (1.4x the interior, against 4x if every tile did its
+// own 16 pixels) into LDS, then every thread transforms one (tile, channel quad).
+constexpr int kGwTY = 4, kGwTX = 8, kGwCS = 32;
+constexpr int kGwPR = 2 * kGwTY + 2, kGwPC = 2 * kGwTX + 2;     // patch rows / cols
+constexpr int kGwLd = kGwCS + 4;                                 // padded pixel stride in LDS (floats)
+
+__device__ __forceinline__ float gw_mish(float x) {              // == mish_f (ops.hip)
+  if (x > 20.f) return x;
+  const float w = __expf(x);
+  const float u = w * (w + 2.f);
+  return x * (u * __frcp_rn(u + 2.f));
+}
+
+__global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restrict__ y, float* __restrict__ V, int B, int H, int W, int C,
+                                                            WinoGnArgs g) {
+  __shared__ __attribute__((aligned(16))) float patch[kGwPR * kGwPC * kGwLd];
+  __shared__ float s_sc[kGwCS], s_sh[kGwCS], s_te[kGwCS];
+  const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
+  const int nslab = C / kGwCS;
+  const int b = blockIdx.z;
+  const int slab = blockIdx.y % nslab, tby = blockIdx.y / nslab, tbx = blockIdx.x;
+  const int c0 = slab * kGwCS;
+  const int ty0 = tby * kGwTY, tx0 = tbx * kGwTX;
+  const int cg = C / kGroups;
+  if (threadIdx.x < kGwCS) {
+    const int c = c0 + threadIdx.x;
+    const double cnt = (double)H * W * cg;
+    const double* st = g.stats + ((long long)b * kGroups + c / cg) * 2;
+    const double mean = st[0] / cnt;
+    double var = st[1] / cnt - mean * mean;
+    if (var < 0) var = 0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float sc = rstd * g.gamma[c];
+    s_sc[threadIdx.x] = sc;
+    s_sh[threadIdx.x] = g.beta[c] - meanf * sc;
+    s_te[threadIdx.x] = g.temb ? g.temb[(long long)b * C + c] : 0.f;
+  }
+  __syncthreads();
+  const float* yb = y + (long long)b * H * W * C + c0;
+  const float* mb = g.mask + (long long)(b % g.mask_bmod) * g.mask_ld;
+  for (int idx = threadIdx.x; idx < kGwPR * kGwPC * (kGwCS / 4); idx += 256) {
+    const int q = idx % (kGwCS / 4), px = idx / (kGwCS / 4);
+    const int pr = px / kGwPC, pc = px - pr * kGwPC;
+    const int iy = 2 * ty0 - 1 + pr, ix = 2 * tx0 - 1 + pc;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      const f32x4 raw = *reinterpret_cast<const f32x4*>(yb + ((long long)iy * W + ix) * C + 4 * q);
+      const float m = mb[ix * g.mask_step];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (gw_mish(raw[k] * s_sc[4 * q + k] + s_sh[4 * q + k]) * m + s_te[4 * q + k]) * m;
+    }
+    *reinterpret_cast<f32x4*>(patch + px * kGwLd + 4 * q) = v;
+  }
+  __syncthreads();
+  const int q = threadIdx.x % (kGwCS / 4), t = threadIdx.x / (kGwCS / 4);
+  const int tr = t / kGwTX, tc = t - tr * kGwTX;
+  const int ty = ty0 + tr, tx = tx0 + tc;
+  if (ty >= th || tx >= tw) return;
+  f32x4 d[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) d[r][qq] = *reinterpret_cast<const f32x4*>(patch + ((2 * tr + r) * kGwPC + 2 * tc + qq) * kGwLd + 4 * q);
+  f32x4 tt[4][4];
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    tt[0][qq] = d[0][qq] - d[2][qq];
+    tt[1][qq] = d[1][qq] + d[2][qq];
+    tt[2][qq] = d[2][qq] - d[1][qq];
+    tt[3][qq] = d[1][qq] - d[3][qq];
+  }
+  const long long plane = (long long)B * th * tw * C;
+  float* vb = V + (((long long)b * th + ty) * tw + tx) * C + c0 + 4 * q;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1], v3 = tt[r][1] - tt[r][3];
+    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 0) * plane) = v0;
+    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 1) * plane) = v1;
+    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 2) * plane) = v2;
+    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 3) * plane) = v3;
+  }
+}
+
+bool gn_wino_input_supported(int C) { return C % kGwCS == 0 && C % kGroups == 0; }
+
+hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s) {
+  if (!gn_wino_input_supported(C) || !g.stats || !g.gamma || !g.beta || !g.mask) return hipErrorInvalidValue;
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  const int gy = ((th + kGwTY - 1) / kGwTY) * (C / kGwCS);
+  if (gy > 65535 || B > 65535) return hipErrorInvalidValue;
+  WinoGnArgs x = g;
+  if (x.mask_bmod < 1) x.mask_bmod = 1;
+  hipLaunchKernelGGL(gn_wino_input_kernel, dim3((tw + kGwTX - 1) / kGwTX, gy, B), dim3(256), 0, s, y, V, B, H, W, C, x);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ out,
                                                           int out_ld, double* __restrict__ stats, int B, int H, int W, int C, WinoOutExtra x) {
   __shared__ double s_g[kGroups][2];
