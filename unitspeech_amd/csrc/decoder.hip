@@ -676,8 +676,15 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
       double* st1 = next_stats(e);
       double* st2 = next_stats(e);
       CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], b.Q[0], st1, e.Bp, F, T, c, e.s));
-      CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, true, b.S1[0], c));
-      CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
+      if (r.c2.w->wino.p && b.wino_v && h->wino_fuse_gn && gn_wino_input_supported(c)) {
+        WinoGnArgs g;       // as in resnet(): block1's GroupNorm + Mish + time embedding inside block2's input transform
+        g.stats = st1; g.gamma = r.g1->buf.p; g.beta = r.b1->buf.p; g.temb = b.tproj + b.tproj_off[r.index];
+        g.mask = e.mask; g.mask_ld = e.T; g.mask_step = 1; g.mask_bmod = e.Bm;
+        CK(conv3x3_wino(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2, &g));
+      } else {
+        CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, true, b.S1[0], c));
+        CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
+      }
       CK(gn_apply(e, b.S2[0], 0, c, st2, r.g2, r.b2, nullptr, b.Q[0], c, false, true, b.P[0], c));
     } else {
       CK(resnet(e, d.r1, cur, cur_ld, b.P[l], c, true));
