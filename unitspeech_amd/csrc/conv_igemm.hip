@@ -1,16 +1,18 @@
 // Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32.
 //
 // Serves every GEMM-shaped op of the U-Net score network (unitspeech/unitspeech.py:124-201):
-//   3x3 Conv2d of Block (:48), 1x1 res_conv (:66) / to_qkv (:83) / to_out (:84, with per-item folded weights),
-//   Downsample 3x3 stride 2 (:30) and Upsample ConvTranspose2d 4x4 stride 2 (:21, as 4 output-phase launches
-//   of a 2x2 tap set).
+//   3x3 Conv2d of Block (:48) -- directly, or as the 16 per-frequency GEMMs of its Winograd F(2x2,3x3) form (wino.hip), with
+//   the output transform optionally inside this kernel (WINO instantiation) --, 1x1 res_conv (:66) / to_qkv (:83) / to_out
+//   (:84, with per-item folded weights), Downsample 3x3 stride 2 (:30) and Upsample ConvTranspose2d 4x4 stride 2 (:21, the 4
+//   output phases of a 2x2 tap set in one launch), and in training the data gradients of all of them.
 // GEMM view: M = output pixels of one item (flattened sub-grid), N = Cout, K = taps * Cin.
 //
-// Workgroup = 256 threads = 4 waves as 2 (M) x 2 (N); tile TM x 128 with TM = 128 (wave tile 64x64 = 2x2 MFMA 32x32
-// blocks) or TM = 64 (wave tile 32x64) for launches that would otherwise leave CUs idle.  K advances in chunks of BK
-// input channels of one tap.  Both operands go global -> LDS directly (global_load_lds_dwordx4, no staging
-// registers, no ds_write): the A rows are gathered per tap through per-lane source addresses (out-of-image taps
-// read a zero page), the B rows come from weights pre-packed as [tap][Cin/BK][Cout][BK] so a tile row is one
+// Workgroup = 256 threads = 4 waves as 2 (M) x 2 (N); tile TM x 128 with TM = 64 (wave tile 32x64; what every launch uses:
+// three co-resident workgroups per CU hide the per-chunk barrier best) or TM = 128 (wave tile 64x64 = 2x2 MFMA 32x32 blocks).
+// K advances in chunks of BK input channels of one tap.  Both operands go global -> LDS directly
+// (`buffer_load_dwordx4 ... offen lds`: SGPR buffer descriptor + 32-bit per-lane byte offset; no staging registers, no
+// ds_write): the A rows are gathered per tap through per-lane offsets, out-of-image taps get an offset beyond the descriptor's
+// range and read zeros; the B rows come from weights pre-packed as [tap][Cin/BK][Cout][BK] so a tile row is one
 // contiguous BK*4-byte line.  The LDS image is lane-linear as the DMA requires; bank conflicts of the
 // ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE side (lane `pos` of a row
 // fetches 16-byte chunk pos ^ swz(row)) and again on the read side, swz(row) = (row / (64/BK)) % (BK/4): the 16
