@@ -26,3 +26,14 @@ def test_finetune_cli_synthetic(tmp_path):
     import torch
     ck = torch.load(tmp_path / "5.pt", map_location="cpu")
     assert set(ck) == {"model", "spk_emb", "mel_min", "mel_max"} and len(ck["model"]) == 230
+
+
+def test_pretrain_step_bench_runs(tmp_path):
+    """bench_pretrain.py (B crops per GPU, fwd + bwd + [all-reduce] + HIP clip+Adam) at a small batch: finite loss, sane JSON."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pretrain.py"), "--batch", "2", "--iters", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["batch_per_gpu"] == 2 and d["value"] > 0 and np.isfinite(d["last_loss"])
+    assert set(d["ms_breakdown"]) == {"fwd", "bwd", "allreduce", "optim"}
