@@ -408,6 +408,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int trow = lane >> 3, tc4 = (lane & 7) * 4;  // read-back role: row trow + 8k, channels tc4..tc4+3
   // WINO with an odd image height / width: the last tile row / column has output positions outside the image
   const bool edge = WINO && (((a.Hout | a.Wout) & 1) != 0);
+  // bias of this wave's two 32-column blocks, loaded ONCE: a global load inside the block loop would make every block wait
+  // (vmcnt retires in order) for the previous block's stores to reach memory
+  float bias_col[2];
+  f32x4 bias_quad[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int ncol = n0 + wn * 64 + nb * 32;
+    bias_col[nb] = (a.bias && ncol + l32 < a.Cout) ? a.bias[ncol + l32] : 0.f;
+    bias_quad[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias && ncol + tc4 < a.Cout) bias_quad[nb] = *reinterpret_cast<const f32x4*>(a.bias + ncol + tc4);
+  }
 #pragma unroll
   for (int yi = 0; yi < NY; ++yi) {
   const f32x16 (&A)[MB][2] = WINO ? Y[yi] : acc;
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       const int ncol = n0 + wn * 64 + nb * 32;
       {   // GroupNorm sums in the native layout (this lane's column, its 16 rows)
         const int n = ncol + l32;
-        const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+        const float bv = bias_col[nb];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dr = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -438,8 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
       }
       const int n = ncol + tc4;
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias && n < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+      const f32x4 b4 = bias_quad[nb];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int dr = trow + 8 * k;
