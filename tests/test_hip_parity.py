@@ -108,14 +108,14 @@ def _model_with_env(cfg, **env):
     return m
 
 
-def test_winograd_forms_agree_bitwise_and_match_direct_convolution(tiny):
+@pytest.mark.parametrize("T", [8, 200])
+def test_winograd_forms_agree_bitwise_and_match_direct_convolution(tiny, T):
     """The three executions of a 3x3 convolution -- Winograd with the output transform inside the GEMM kernel, Winograd with
     separate transform passes, direct implicit GEMM -- on a ragged input whose level-3 width is odd (partial last tile):
     the two Winograd forms agree bit for bit (the library picks between them by launch size, i.e. by batch), the direct form
     agrees to rounding, and all match the CPU oracle."""
-    _, sd = tiny
-    T = 200                                                                   # widths 200 / 100 / 50 / 25
-    inp = G(synthetic_inputs(TINY, 3, T, seed=31, lengths=[T, T - 13, 64]))
+    _, sd = tiny                                                              # T = 200: widths 200 / 100 / 50 / 25; T = 8: 8 / 4 / 2 / 1
+    inp = G(synthetic_inputs(TINY, 3, T, seed=31, lengths=[T, max(T - 13, 3), min(64, T)]))
     t = torch.tensor([0.21, 0.55, 0.93])
     args = [inp[k].to(DEV) for k in ("z", "mask", "cond")] + [t.to(DEV), inp["spk_emb"].to(DEV)]
     outs = {}
@@ -406,3 +406,18 @@ def test_baseline_size_sampler_properties(full):
     assert torch.equal(a[1:], one)
     assert torch.isfinite(a).all()
     assert (a.cpu() * (1 - inp["mask"])).abs().max().item() == 0.0
+
+
+def test_long_utterance_properties(full):
+    """4x the BASELINE length (80x4096, full-size weights, ragged pair): finite, masked frames exactly zero, run-to-run identical,
+    and the first item equal to its single-utterance run (per-item offsets stay below the 2 GiB buffer-descriptor range)."""
+    model, _ = full
+    T = 4096
+    inp = G(synthetic_inputs(FULL, 2, T, seed=77, lengths=[T, T - 1000]))
+    args = [inp[k].to(DEV) for k in ("z", "mask", "cond", "spk_emb")]
+    a = model(*args, 1, 1.0, 1.0, rng="philox", seed=3)
+    b = model(*args, 1, 1.0, 1.0, rng="philox", seed=3)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert (a.cpu() * (1 - inp["mask"])).abs().max().item() == 0.0
+    one = model(*(t[:1] for t in args), 1, 1.0, 1.0, rng="philox", seed=3)
+    assert torch.equal(a[:1], one)
