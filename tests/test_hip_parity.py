@@ -421,3 +421,23 @@ def test_long_utterance_properties(full):
     assert (a.cpu() * (1 - inp["mask"])).abs().max().item() == 0.0
     one = model(*(t[:1] for t in args), 1, 1.0, 1.0, rng="philox", seed=3)
     assert torch.equal(a[:1], one)
+
+
+def test_split_precision_winograd_gemm_switch(full):
+    """US_WINO_BF16X6=1 (experimental, off by default): the Winograd GEMMs of the two low-resolution levels as six bf16 MFMA
+    products of three-way split operands with fp32 accumulation.  Must stay at the fp32 path's error level against the oracle and
+    keep batch composition out of the result."""
+    _, sd = full
+    m = _model_with_env(FULL, US_WINO_BF16X6=1)
+    T = 64
+    inp = G(synthetic_inputs(FULL, 3, T, seed=41, lengths=[T, T - 5, 40]))
+    t = torch.tensor([0.3, 0.6, 0.9])
+    args = [inp[k].to(DEV) for k in ("z", "mask", "cond")] + [t.to(DEV), inp["spk_emb"].to(DEV)]
+    with torch.no_grad():
+        out = m.estimator(*args)
+        one = m.estimator(*(a[1:2] for a in args))
+    ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["cond"], t, inp["spk_emb"])
+    e = l1(out, ref)
+    print(f"\nbf16x6 switch: estimator L1 vs oracle {e:.3e}")
+    assert e <= 2e-6
+    assert torch.equal(out[1:2], one)

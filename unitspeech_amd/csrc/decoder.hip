@@ -38,6 +38,8 @@ struct Slot {
   DevBuf dg;             // conv kinds (and to_out): repack for the data-gradient GEMM [tap][Cout/bk_dg][Cin][bk_dg]
   int bk_dg = 0;
   DevBuf wino;           // 3x3 stride-1 convs of the Winograd levels: U = G g G^T, [16][Cin/bk][Cout][bk]
+  DevBuf wino_bf;        // experimental: U as three bf16 planes [3][16][Cout][Cin] (n counts floats of storage)
+  int level = -1;        // U-Net level of a ResnetBlock conv
   DevBuf wino_dg;        // ... and of the rotated, channel-swapped filter for the data gradient, [16][Cout/bk_dg][Cin][bk_dg]
   bool want_wino = false;
   bool dg_as_1x1 = false;  // RAW [Cout][Cin][1][1] tensor that also needs a dgrad pack (attention to_out)
@@ -91,6 +93,8 @@ struct us_decoder {
   Slot *final_g, *final_b, *final_w1, *final_b1;
   Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
   int n_resnets = 0;
+  bool bf16x6 = false;       // US_WINO_BF16X6=1 (experimental): the Winograd GEMMs of levels >= bf16x6_min_level as six bf16 MFMA
+  int bf16x6_min_level = 2;  // products of split operands (wino_gemm.hip); always the separate-transform form there
   long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
   int wino_min_level = 0;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
@@ -170,6 +174,8 @@ struct us_decoder {
       if (!r.first) r.c1.w->want_wino = true;
       r.c2.w->want_wino = true;
     }
+    if (!r.first) r.c1.w->level = level;
+    r.c2.w->level = level;
     r.has_res = cin != cout;
     if (r.has_res) {
       if (r.first) {
@@ -350,6 +356,7 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false
   need_r(h->mid1); need_r(h->mid2);
   for (auto& u : h->ups) { need_r(u.r1); need_r(u.r2); }
   need(h->final_conv3, 0);
+  if (h->bf16x6) wv += wv / 2;          // three bf16 planes = 6 bytes per V element
   if (wv) { b.wino_v = A.alloc<float>(wv); b.wino_m = A.alloc<float>(wm); }
 }
 
@@ -422,10 +429,34 @@ struct WinoEpi {
   bool mask_out = false;
 };
 hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int K, int N, int bk, int level, float* out, int out_ld,
-                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr) {
+                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr, const void* Ubf = nullptr) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   Buffers& b = *e.b;
+  if (Ubf) {
+    // experimental split-precision form: V as three bf16 planes, six-product GEMM on the bf16 matrix cores, separate output transform
+    hipError_t e0 = gn ? (in_ld == K ? launch_gn_wino_input(in, b.wino_v, e.Bp, H, W, K, *gn, e.s, true) : hipErrorInvalidValue)
+                       : launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, e.s, true);
+    if (e0 != hipSuccess) return e0;
+    const int rows = e.Bp * th * tw;
+    us_decoder* h = e.h;
+    if (!h->prof_active) {
+      e0 = launch_wino_gemm_bf16x6(b.wino_v, Ubf, b.wino_m, rows, N, K, e.s);
+    } else {
+      us_decoder::ProfRec r;
+      r.a = h->prof_event(); r.b = h->prof_event(); r.kind = 0;
+      r.flops = 2.0 * 16 * (double)rows * N * (double)K;
+      (void)hipEventRecord(r.a, e.s);
+      e0 = launch_wino_gemm_bf16x6(b.wino_v, Ubf, b.wino_m, rows, N, K, e.s);
+      (void)hipEventRecord(r.b, e.s);
+      h->prof_pending.push_back(r);
+    }
+    if (e0 != hipSuccess) return e0;
+    WinoOutExtra x{};
+    x.add = ep.add; x.add_ld = ep.add_ld;
+    if (ep.mask_out) { x.mask = e.mask; x.mask_ld = e.T; x.mask_step = 1 << level; x.mask_bmod = e.Bm; }
+    return launch_wino_output(b.wino_m, ep.bias, out, out_ld, ep.stats, e.Bp, H, W, N, e.s, &x);
+  }
   // gn: `in` is block1's raw conv output (ld == K); its GroupNorm + Mish + time embedding are evaluated inside the transform
   hipError_t err = gn ? (in_ld == K ? launch_gn_wino_input(in, b.wino_v, e.Bp, H, W, K, *gn, e.s) : hipErrorInvalidValue)
                       : launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, e.s);
@@ -480,7 +511,7 @@ hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, 
   WinoEpi ep;
   ep.bias = w.b ? w.b->buf.p : nullptr;
   ep.stats = stats;
-  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn);
+  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn, w.w->wino_bf.p);
 }
 
 hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
@@ -825,6 +856,8 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS")) h->wino_fuse_min_wgs = atoll(wf);
+  if (const char* wf = getenv("US_WINO_BF16X6")) h->bf16x6 = atoi(wf) != 0;
+  if (const char* wf = getenv("US_WINO_BF16X6_MIN_LEVEL")) h->bf16x6_min_level = atoi(wf);
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
   h->build();
   {
@@ -852,9 +885,13 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
       ok = hipMalloc(reinterpret_cast<void**>(&s->wino.p), s->wino.n * sizeof(float)) == hipSuccess &&
            hipMalloc(reinterpret_cast<void**>(&s->wino_dg.p), s->wino_dg.n * sizeof(float)) == hipSuccess;
     }
+    if (ok && s->want_wino && h->bf16x6 && s->level >= h->bf16x6_min_level && wino_gemm_bf16x6_supported((int)s->shape[0], (int)s->shape[1])) {
+      s->wino_bf.n = (size_t)24 * s->shape[0] * s->shape[1];          // 3 planes x 16 frequencies of bf16 = 96 bytes per (co, ci)
+      ok = hipMalloc(reinterpret_cast<void**>(&s->wino_bf.p), s->wino_bf.n * sizeof(float)) == hipSuccess;
+    }
     if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); }
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); if (t->wino_bf.p) (void)hipFree(t->wino_bf.p); }
       return US_EHIP;
     }
   }
@@ -864,7 +901,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); }
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); if (s->wino_bf.p) (void)hipFree(s->wino_bf.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
@@ -902,6 +939,7 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
     case Kind::CONV_OIHW:
       // a conv that runs in the Winograd domain never reads its direct-form pack (conv3x3 takes the Winograd branch whenever
       // wino.p is set; every workspace plan of this handle then has the V/M scratch)
+      if (s->wino_bf.p) US_HIP(h, launch_wino_pack_weight_bf16(data, s->wino_bf.p, (int)s->shape[0], (int)s->shape[1], st));
       if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
       if (s->wino_dg.p) US_HIP(h, launch_wino_pack_weight(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], s->bk_dg, st, true));

@@ -216,7 +216,8 @@ namespace us {
 // dgrad = true: the transform of the 180-degree-rotated, channel-swapped filter (data gradient), dst[16][Cout/bk][Cin][bk]
 hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s, bool dgrad = false);
 // x: [B][H][W][x_ld] (C channels) -> V: [16][B][th][tw][C], th = ceil(H/2), tw = ceil(W/2); zero padding outside the image
-hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s);
+// split = true: V is written as three bf16 planes [3][16][B][th][tw][C] (v = v1 + v2 + v3) for the bf16x6 GEMM (wino_gemm.hip)
+hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s, bool split = false);
 // V of d = (mish(GroupNorm(y)) * mask + temb) * mask, y a raw conv output [B][H][W][C] (ld = C): block1's gn_apply of a
 // ResnetBlock folded into the input transform of its second convolution (C a multiple of 32)
 struct WinoGnArgs {
@@ -225,7 +226,7 @@ struct WinoGnArgs {
   const float* mask; int mask_ld, mask_step, mask_bmod;
 };
 bool gn_wino_input_supported(int C);
-hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s);
+hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s, bool split = false);
 // M: [16][B][th][tw][C] -> out[B][H][W][out_ld] = A^T M A + bias; optional GroupNorm partial sums [B][8][2] of the result
 // optional epilogue of the separate output transform: out = (Y + bias + add) * mask  (data gradients: residual sum + frame mask)
 struct WinoOutExtra {
@@ -234,4 +235,9 @@ struct WinoOutExtra {
 };
 hipError_t launch_wino_output(const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
                               hipStream_t s, const WinoOutExtra* extra = nullptr);
+// ---- experimental bf16x6 Winograd GEMM (wino_gemm.hip) ---------------------------------------------------------------------
+bool wino_gemm_bf16x6_supported(int N, int K);
+// V: [3][16][rows][K] bf16 planes, U: [3][16][N][K] bf16 planes, M: [16][rows][N] fp32
+hipError_t launch_wino_gemm_bf16x6(const void* V, const void* U, float* M, int rows, int N, int K, hipStream_t s);
+hipError_t launch_wino_pack_weight_bf16(const float* src, void* dst, int Cout, int Cin, hipStream_t s);
 }  // namespace us

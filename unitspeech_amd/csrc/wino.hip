@@ -10,7 +10,32 @@ namespace us {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- split-precision storage of V (experimental bf16x6 GEMM path, wino_gemm.hip) -------------------------------------------
+// SPLIT = true: V is kept as three bf16 planes v = v1 + v2 + v3 (8 significant bits each), plane stride `psplit` elements; the
+// GEMM then forms the six products of order >= 2^-16 on the bf16 matrix cores with fp32 accumulation (fp32-level error).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <bool SPLIT>
+__device__ __forceinline__ void store_v(float* __restrict__ V, long long idx, long long psplit, const f32x4& v) {
+  if (!SPLIT) {
+    *reinterpret_cast<f32x4*>(V + idx) = v;
+  } else {
+    __bf16* vb = reinterpret_cast<__bf16*>(V);
+    bf16x4 p1, p2, p3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const __bf16 a1 = (__bf16)v[k];
+      const float r1 = v[k] - (float)a1;
+      const __bf16 a2 = (__bf16)r1;
+      p1[k] = a1; p2[k] = a2; p3[k] = (__bf16)(r1 - (float)a2);
+    }
+    *reinterpret_cast<bf16x4*>(vb + idx) = p1;
+    *reinterpret_cast<bf16x4*>(vb + psplit + idx) = p2;
+    *reinterpret_cast<bf16x4*>(vb + 2 * psplit + idx) = p3;
+  }
+}
+
 // one thread = one (tile, channel quad); grid (blocks, B)
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ V, int B, int H, int W,
                                                          int C) {
   const int C4 = C >> 2;
@@ -44,26 +69,27 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       tt[2][q] = d[2][q] - d[1][q];
       tt[3][q] = d[1][q] - d[3][q];
     }
-    float* vb = V + (((long long)b * th + ty) * tw + tx) * C + c;
+    const long long vi = (((long long)b * th + ty) * tw + tx) * C + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       // columns: v = t B
       f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1], v3 = tt[r][1] - tt[r][3];
-      *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 0) * plane) = v0;
-      *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 1) * plane) = v1;
-      *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 2) * plane) = v2;
-      *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 3) * plane) = v3;
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, 16 * plane, v0);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, 16 * plane, v1);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, 16 * plane, v2);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, 16 * plane, v3);
     }
   }
 }
 
-hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s) {
+hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s, bool split) {
   if (C % 4 != 0 || x_ld % 4 != 0) return hipErrorInvalidValue;
   const long long per_item = (long long)((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   int blocks = (int)((per_item + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wino_input_kernel, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C);
+  if (split) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C);
+  else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C);
   return hipGetLastError();
 }
 
@@ -83,6 +109,7 @@ __device__ __forceinline__ float gw_mish(float x) {              // == mish_f (o
   return x * (u * __frcp_rn(u + 2.f));
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restrict__ y, float* __restrict__ V, int B, int H, int W, int C,
                                                             WinoGnArgs g) {
   __shared__ __attribute__((aligned(16))) float patch[kGwPR * kGwPC * kGwLd];
@@ -142,27 +169,28 @@ __global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restr
     tt[3][qq] = d[1][qq] - d[3][qq];
   }
   const long long plane = (long long)B * th * tw * C;
-  float* vb = V + (((long long)b * th + ty) * tw + tx) * C + c0 + 4 * q;
+  const long long vi = (((long long)b * th + ty) * tw + tx) * C + c0 + 4 * q;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1], v3 = tt[r][1] - tt[r][3];
-    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 0) * plane) = v0;
-    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 1) * plane) = v1;
-    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 2) * plane) = v2;
-    *reinterpret_cast<f32x4*>(vb + (long long)(r * 4 + 3) * plane) = v3;
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, 16 * plane, v0);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, 16 * plane, v1);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, 16 * plane, v2);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, 16 * plane, v3);
   }
 }
 
 bool gn_wino_input_supported(int C) { return C % kGwCS == 0 && C % kGroups == 0; }
 
-hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s) {
+hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s, bool split) {
   if (!gn_wino_input_supported(C) || !g.stats || !g.gamma || !g.beta || !g.mask) return hipErrorInvalidValue;
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   const int gy = ((th + kGwTY - 1) / kGwTY) * (C / kGwCS);
   if (gy > 65535 || B > 65535) return hipErrorInvalidValue;
   WinoGnArgs x = g;
   if (x.mask_bmod < 1) x.mask_bmod = 1;
-  hipLaunchKernelGGL(gn_wino_input_kernel, dim3((tw + kGwTX - 1) / kGwTX, gy, B), dim3(256), 0, s, y, V, B, H, W, C, x);
+  if (split) hipLaunchKernelGGL(gn_wino_input_kernel<true>, dim3((tw + kGwTX - 1) / kGwTX, gy, B), dim3(256), 0, s, y, V, B, H, W, C, x);
+  else hipLaunchKernelGGL(gn_wino_input_kernel<false>, dim3((tw + kGwTX - 1) / kGwTX, gy, B), dim3(256), 0, s, y, V, B, H, W, C, x);
   return hipGetLastError();
 }
 
