@@ -8,6 +8,7 @@
 // Per frequency f:  M_f [rows][N] = V_f [rows][K] . U_f [N][K]^T,  rows = B * tiles (the items of a frequency are contiguous).
 // Workgroup tile 128 x 128, 4 waves of 64 x 64, K in chunks of 32: operands go global -> registers -> LDS (padded 80-byte rows:
 // conflict-free 16-byte fragment reads), the next chunk's global loads are issued before the current chunk's MFMAs.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace us {
@@ -108,11 +109,122 @@ __global__ __launch_bounds__(256) void wino_gemm_bf16x6_kernel(const __bf16* __r
       }
 }
 
+// Big-tile form: 256 x 256 per workgroup, 8 waves of 64 (rows) x 128 (columns), dynamic LDS (2 x 3 x 256 x 80 B = 120 KB, one
+// workgroup per CU).  The 128 x 128 kernel above reads (128 + 128) operand rows per 16,384 outputs, i.e. 48 KB per 1,536 MFMA cycles
+// and workgroup -- with two workgroups per CU that is the 64 B/clk a CU can take from L2, which is what holds it at 40 % of the
+// six-product rate; this one reads half as much per output.
+__global__ __launch_bounds__(512) void wino_gemm_bf16x6_big_kernel(const __bf16* __restrict__ V, const __bf16* __restrict__ U, float* __restrict__ M,
+                                                                   int rows, int N, int K) {
+  constexpr int BT = 256;
+  extern __shared__ __attribute__((aligned(16))) __bf16 big_smem[];
+  __bf16 (*As)[BT][GLDK] = reinterpret_cast<__bf16 (*)[BT][GLDK]>(big_smem);
+  __bf16 (*Bs)[BT][GLDK] = reinterpret_cast<__bf16 (*)[BT][GLDK]>(big_smem + 3 * BT * GLDK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, hh = lane >> 5;       // 4 x 2 waves
+  const int f = blockIdx.z;
+  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  const long long planeV = 16LL * rows * K, planeU = 16LL * N * K;
+  const __bf16* Vf = V + (long long)f * rows * K;
+  const __bf16* Uf = U + (long long)f * N * K;
+  const int srow = tid >> 2, sseg = (tid & 3) * 8;        // 128 rows x 4 segments per pass, two passes per plane and operand
+  int ar[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = m0 + srow + 128 * h;
+    ar[h] = r < rows ? r : rows - 1;
+  }
+  bf16x8 ra[3][2], rb[3][2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ra[p][h] = *reinterpret_cast<const bf16x8*>(Vf + p * planeV + (long long)ar[h] * K + k0 + sseg);
+        rb[p][h] = *reinterpret_cast<const bf16x8*>(Uf + p * planeU + (long long)(n0 + srow + 128 * h) * K + k0 + sseg);
+      }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<bf16x8*>(&As[p][srow + 128 * h][sseg]) = ra[p][h];
+        *reinterpret_cast<bf16x8*>(&Bs[p][srow + 128 * h][sseg]) = rb[p][h];
+      }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += GBK) {
+    lstore();
+    __syncthreads();
+    if (k0 + GBK < K) gload(k0 + GBK);
+#pragma unroll
+    for (int s = 0; s < GBK / 16; ++s) {
+      bf16x8 a[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(&As[p][wm * 64 + i * 32 + l32][s * 16 + 8 * hh]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&Bs[p][wn * 128 + j * 32 + l32][s * 16 + 8 * hh]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* Mf = M + (long long)f * rows * N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int col = n0 + wn * 128 + j * 32 + l32;
+        if (row < rows) Mf[(long long)row * N + col] = acc[i][j][r];
+      }
+}
+
 bool wino_gemm_bf16x6_supported(int N, int K) { return N % GT == 0 && K % GBK == 0; }
 
 // V: [3][16][rows][K] bf16, U: [3][16][N][K] bf16, M: [16][rows][N] fp32
 hipError_t launch_wino_gemm_bf16x6(const void* V, const void* U, float* M, int rows, int N, int K, hipStream_t s) {
   if (!wino_gemm_bf16x6_supported(N, K) || rows <= 0) return hipErrorInvalidValue;
+  static int big = -1;
+  if (big < 0) { const char* e = getenv("US_BF16X6_BIG"); big = e ? atoi(e) : 1; }
+  if (big && N % 256 == 0) {
+    static bool attr = false;
+    const int lds = 2 * 3 * 256 * GLDK * (int)sizeof(__bf16);
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_bf16x6_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    dim3 g2(N / 256, (rows + 255) / 256, 16);
+    hipLaunchKernelGGL(wino_gemm_bf16x6_big_kernel, g2, dim3(512), lds, s, reinterpret_cast<const __bf16*>(V), reinterpret_cast<const __bf16*>(U), M,
+                       rows, N, K);
+    return hipGetLastError();
+  }
   dim3 grid(N / GT, (rows + GT - 1) / GT, 16);
   hipLaunchKernelGGL(wino_gemm_bf16x6_kernel, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(V), reinterpret_cast<const __bf16*>(U), M, rows,
                      N, K);
