@@ -211,7 +211,7 @@ bool wino_gemm_bf16x6_supported(int N, int K) { return N % GT == 0 && K % GBK ==
 hipError_t launch_wino_gemm_bf16x6(const void* V, const void* U, float* M, int rows, int N, int K, hipStream_t s) {
   if (!wino_gemm_bf16x6_supported(N, K) || rows <= 0) return hipErrorInvalidValue;
   static int big = -1;
-  if (big < 0) { const char* e = getenv("US_BF16X6_BIG"); big = e ? atoi(e) : 1; }
+  if (big < 0) { const char* e = getenv("US_BF16X6_BIG"); big = e ? atoi(e) : 1; }      // 0: 128 x 128 tiles, 1: 256 x 256
   if (big && N % 256 == 0) {
     static bool attr = false;
     const int lds = 2 * 3 * 256 * GLDK * (int)sizeof(__bf16);
