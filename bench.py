@@ -6,9 +6,11 @@ evaluations per step) over a batch of synthetic utterances that is already resid
 is BASELINE.json configs[1]: B=1, 80x1024 mel.  With --gpus N every rank runs the same per-GPU workload on its own
 utterances (weak scaling, no data-path collective; the decoder weights are broadcast once from rank 0 over RCCL).
 
-Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+Launch:  python bench.py [--gpus N] [--steps K] [--warmup W]      (N > 1 without a launcher: bench.py starts its own N ranks
+                                                                   through torch.distributed.run before touching the GPU)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
                 bench.py --gpus N --steps K --warmup W
+         python bench.py --config 64x8                              (BASELINE.json configs[4]: 64 utterances/GPU x 8 GPUs)
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -34,18 +36,63 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 HOP, SR = 256, 22050              # conf/hydra_config.py:37,39  -> seconds of speech per mel frame
 
 
-def parse():
+CONFIGS = {            # BASELINE.json configs -> (utterances per GPU, GPUs)
+    "1x1": (1, 1),     # configs[1]: B=1, the bench line
+    "64x1": (64, 1),   # configs[2]: B=64 on one GPU (roofline run)
+    "64x8": (64, 8),   # configs[4]: B=512 sharded over 8 GPUs
+}
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE.json config shorthand: utterances/GPU x GPUs")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (configs[1]: 1; configs[2]/[4]: 64)")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (configs[1]: 1; configs[2]/[4]: 64)")
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--diffusion-steps", type=int, default=50)
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="diffusion steps timed on the host CPU")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    cb, cg = CONFIGS[a.config] if a.config else (1, 1)
+    if a.batch is None:
+        a.batch = cb
+    if a.gpus is None:
+        a.gpus = cg
+    if a.gpus < 1 or a.batch < 1:
+        ap.error("--gpus and --batch must be >= 1")
+    return a
+
+
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` with no launcher in the environment: start N ranks (one per GPU) as a child
+    `torch.distributed.run` and return its exit code.  Runs BEFORE this process makes any GPU call (importing torch does not
+    initialise HIP), so no initialised process is ever replaced or forked."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = [x for x in sys.argv[1:]]
+    if "--gpus" not in " ".join(argv):
+        argv += ["--gpus", str(a.gpus)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cfg, frames, n_diff, steps_timed):
@@ -71,100 +118,127 @@ def cpu_baseline(cfg, frames, n_diff, steps_timed):
         O.reverse_diffusion(sd, inp["z"], inp["mask"], inp["cond"], inp["spk_emb"], steps_timed, 1.0, 1.0, noise=inp["noise"])
         dt = time.perf_counter() - t0
     per_step = dt / steps_timed
-    return {"value": frames / (per_step * n_diff), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+    return {"value": frames / (per_step * n_diff), "unit": "mel-frames/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
             "sample": f"{steps_timed} of {n_diff} diffusion steps (3 score evaluations each) of the B=1 80x{frames} workload, "
                       f"{dt:.1f} s measured, scaled linearly",
             "sec_per_diffusion_step": per_step}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU: the HIP decoder has no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+class HipWorkload:
+    """One rank's share of the job on the HIP decoder: its utterances resident in HBM, one `step()` = one complete
+    `UnitSpeech.forward` over them.  (The gloo test of the N>1 path substitutes a CPU stand-in with the same four methods.)"""
+
+    def __init__(self, cfg, sd, device, a, rank):
+        self.model = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
+        self.model = self.model.to(device).eval()
+        self.model.load_state_dict(sd, strict=True)
+        self.model.micro_batch = a.micro_batch
+        self.device, self.a, self.rank = device, a, rank
+        # this rank's shard of utterances: items [rank*B, (rank+1)*B) of the global batch, resident in HBM
+        self.inp = {k: torch.from_numpy(v).to(device) for k, v in synthetic_inputs(cfg, a.batch, a.frames, seed=1000 + rank).items()}
+        self.eng = None
+
+    def step(self):
+        i, a = self.inp, self.a
+        return self.model(i["z"], i["mask"], i["cond"], i["spk_emb"], a.diffusion_steps, 1.0, 1.0, rng="philox", seed=1234,
+                          utt_offset=self.rank * a.batch)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def profile_begin(self):
+        self.eng = self.model._sync(self.device)      # creates the handle / pushes the weights when no warm-up step has run yet
+        self.eng.lib.us_profile_enable(self.eng.handle, 1)
+        self.eng.lib.us_profile_read(self.eng.handle, None, None, None, None, None, 1)
+
+    def profile_end(self):
+        conv_ms, conv_fl, ev_ms = C.c_double(), C.c_double(), C.c_double()
+        conv_n, ev_n = C.c_int64(), C.c_int64()
+        lib, h = self.eng.lib, self.eng.handle
+        lib.us_profile_read(h, C.byref(conv_ms), C.byref(conv_fl), C.byref(conv_n), C.byref(ev_ms), C.byref(ev_n), 1)
+        lib.us_profile_enable(h, 0)
+        return {"conv_ms": conv_ms.value, "conv_flops": conv_fl.value, "conv_launches": int(conv_n.value), "eval_ms": ev_ms.value,
+                "evals": int(ev_n.value), "flops_eval_item": lib.us_estimator_flops(h, self.a.frames)}
+
+
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed counter summary (separate rocprofv3 --pmc passes, tools/pmc_traffic.py), with
+    the commit it was measured at: a constant of that commit, not of the run that prints it."""
+    for name in ("r02_pmc_summary.json", "pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                return d.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "commit": d.get("commit")}
+            except Exception:
+                pass
+    return None, None
+
+
+def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, device=None):
+    """One rank of the job; rank 0 returns the result dict, the others None."""
+    if device is None:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if not dist.is_initialized():
+            kw = {"device_id": device} if backend == "nccl" else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
-    cfg = DecoderConfig()
+    cfg = a.cfg if getattr(a, "cfg", None) is not None else DecoderConfig()
     B, T, N = a.batch, a.frames, a.diffusion_steps
     # rank 0 generates the synthetic checkpoint; the others receive it as ONE packed 476.6 MB fp32 blob over RCCL
     sd = broadcast_state_dict(cfg, synthetic_state_dict(cfg, 0) if rank == 0 else None, rank, world, device)
-    model = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
-    model = model.to(device).eval()
-    model.load_state_dict(sd, strict=True)
-    model.micro_batch = a.micro_batch
+    wl = workload_cls(cfg, sd, device, a, rank)
     del sd
 
-    # this rank's shard of utterances: items [rank*B, (rank+1)*B) of the global batch, resident in HBM
-    inp = {k: torch.from_numpy(v).to(device) for k, v in synthetic_inputs(cfg, B, T, seed=1000 + rank).items()}
-
-    def step():
-        return model(inp["z"], inp["mask"], inp["cond"], inp["spk_emb"], N, 1.0, 1.0, rng="philox", seed=1234,
-                     utt_offset=rank * B)
-
+    out = None
     for _ in range(a.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    eng = model._sync(device)          # creates the handle / pushes the weights when no warm-up step has run yet
-    eng.lib.us_profile_enable(eng.handle, 1)
-    eng.lib.us_profile_read(eng.handle, None, None, None, None, None, 1)
+        out = wl.step()
+    wl.sync()
+    wl.profile_begin()
 
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    wl.sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
+        out = wl.step()
+    wl.sync()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, world, device)
-    assert torch.isfinite(out).all(), "non-finite decoder output"
+    assert out is None or torch.isfinite(out).all(), "non-finite decoder output"
+    prof = wl.profile_end()
 
-    conv_ms, conv_fl, ev_ms = C.c_double(), C.c_double(), C.c_double()
-    conv_n, ev_n = C.c_int64(), C.c_int64()
-    eng.lib.us_profile_read(eng.handle, C.byref(conv_ms), C.byref(conv_fl), C.byref(conv_n), C.byref(ev_ms), C.byref(ev_n), 1)
-    eng.lib.us_profile_enable(eng.handle, 0)
-
+    res = None
     if rank == 0:
         frames_total = world * B * T * a.steps
         value = frames_total / elapsed
         ms_per_step = 1e3 * elapsed / a.steps
         n_cfg = 3
-        flops_eval_item = eng.lib.us_estimator_flops(eng.handle, T)
-        flops_step = flops_eval_item * n_cfg * B * N
+        flops_step = prof["flops_eval_item"] * n_cfg * B * N
         # dominant kernel: conv_igemm_kernel<32> (every 3x3 / 1x1 / strided / transposed convolution of the U-Net)
-        launches = max(int(conv_n.value), 1)
-        avg_ms = conv_ms.value / launches
-        flops_per_launch = conv_fl.value / launches
+        launches = max(prof["conv_launches"], 1)
+        avg_ms = prof["conv_ms"] / launches
+        flops_per_launch = prof["conv_flops"] / launches
         achieved = (flops_per_launch / (avg_ms * 1e-3)) / 1e12 if avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic()
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
                     "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches_sampled": launches,
-                    "conv_share_of_eval_time": (conv_ms.value / ev_ms.value) if ev_ms.value > 0 else None,
-                    "sampled_eval_ms": (ev_ms.value / max(int(ev_n.value), 1)),
+                    "conv_share_of_eval_time": (prof["conv_ms"] / prof["eval_ms"]) if prof["eval_ms"] > 0 else None,
+                    "sampled_eval_ms": (prof["eval_ms"] / max(prof["evals"], 1)),
                     # achieved counts the FLOPs the MFMA units EXECUTE (the Winograd GEMMs at their 2.25x reduced count);
                     # whole_job_tflops is the direct-convolution count of SURVEY.md 8(d) over wall time, which the
                     # Winograd levels push past what the matrix cores execute
                     "flops_basis": "executed MFMA FLOPs per conv_igemm launch (Winograd F(2x2,3x3) GEMMs at their reduced count)",
                     "whole_job_tflops": flops_step * world / (ms_per_step * 1e-3) / 1e12}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
         res = {"metric": "mel-frames/sec @ 50 diffusion steps, 80x1024", "value": value, "unit": "mel-frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -175,9 +249,26 @@ def main():
                "roofline": roofline}
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, T, N, a.cpu_baseline_steps)
-        print(json.dumps(res))
-    if dist is not None:
+    if dist is not None and backend == "nccl":
         dist.destroy_process_group()
+    return res
+
+
+def main():
+    a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(spawn_ranks(a))       # no launcher: start our own ranks; nothing in this process has touched the GPU
+    world = int(env_world) if env_world is not None else 1
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} disagrees with WORLD_SIZE={world} set by the launcher")
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP decoder has no CPU fallback")
+    res = run_rank(a, rank, local, world)
+    if res is not None:
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":

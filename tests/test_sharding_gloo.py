@@ -84,3 +84,77 @@ def test_two_rank_gradient_allreduce(tmp_path):
     want = np.concatenate([np.full(12, 1.5), np.full(7, 3.0), np.full(8, 4.5), np.full(5, 15.0), [2.0]]).astype(np.float32)
     for k in range(world):
         np.testing.assert_allclose(r[k], want, rtol=0, atol=0)           # mean of ranks 1x and 2x; 2 collectives
+
+
+# ---- bench.py's N>1 path: rank function end to end on 2 gloo ranks with the engine replaced at the model call ----------------
+class _FakeWorkload:
+    """Stand-in for bench.HipWorkload (same four methods): checks the broadcast weights arrived and burns a rank-dependent time."""
+
+    def __init__(self, cfg, sd, device, a, rank):
+        self.rank, self.a = rank, a
+        self.checksum = float(sum(v.double().abs().sum() for v in sd.values()))
+        self.calls = 0
+
+    def step(self):
+        import time
+        self.calls += 1
+        time.sleep(0.02 * (1 + self.rank))                 # rank 1 is the slow one: the job time must be ITS time
+        return torch.zeros(self.a.batch, 80, self.a.frames)
+
+    def sync(self):
+        pass
+
+    def profile_begin(self):
+        pass
+
+    def profile_end(self):
+        return {"conv_ms": 1.0, "conv_flops": 1e9, "conv_launches": 10, "eval_ms": 2.0, "evals": 1, "flops_eval_item": 1e9}
+
+
+def _bench_worker(rank, world, port, out_dir):
+    import json
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    a = bench.parse(["--gpus", str(world), "--batch", "3", "--frames", "64", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"])
+    a.cfg = CFG
+    res = bench.run_rank(a, rank, rank, world, backend="gloo", workload_cls=_FakeWorkload, device=torch.device("cpu"))
+    with open(os.path.join(out_dir, f"b{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_bench_rank_function_two_gloo_ranks(tmp_path):
+    import json
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = json.load(open(tmp_path / "b0.json"))
+    assert json.load(open(tmp_path / "b1.json")) is None             # only rank 0 reports
+    assert r0["n_gpus"] == 2 and r0["steps"] == 4 and r0["scaling"] == "weak"
+    # value = frames of ALL ranks / max-over-ranks time: rank 1 sleeps 40 ms per step
+    assert r0["ms_per_step"] >= 40.0
+    assert abs(r0["value"] - 2 * 3 * 64 * 4 / (r0["ms_per_step"] * 4e-3)) <= 1e-6 * r0["value"]
+    assert "roofline" in r0 and "cpu_baseline" not in r0
+
+
+def test_bench_spawns_its_own_ranks_and_refuses_mismatch(monkeypatch):
+    import subprocess
+    import sys
+    import bench
+    import pytest
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "64x8", "--steps", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd
+    assert cmd[cmd.index("--gpus") + 1] == "8" and "--config" in cmd
+    # a launcher's WORLD_SIZE that disagrees with --gpus is refused, also when it is 1
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "disagrees" in str(e.value.code)

@@ -199,7 +199,8 @@ def _normal(seed: int, name: str, shape: Sequence[int], std: float = 1.0) -> np.
     return (_rng(seed, name).standard_normal(size=tuple(shape), dtype=np.float32) * np.float32(std)).astype(np.float32)
 
 
-def synthetic_state_dict(cfg: DecoderConfig, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+def synthetic_state_dict(cfg: DecoderConfig, seed: int = 0, rezero_g: float = REZERO_G,
+                         qkv_scale: float = QKV_SCALE) -> "OrderedDict[str, np.ndarray]":
     """Deterministic fp32 weights keyed by (seed, name).
 
     Scale follows torch's default conv/linear init (uniform(+-1/sqrt(fan_in)) for weight and bias);
@@ -216,7 +217,7 @@ def synthetic_state_dict(cfg: DecoderConfig, seed: int = 0) -> "OrderedDict[str,
         elif name == "spk_uncon":
             out[name] = _normal(seed, name, shape, 1.0)
         elif name.endswith(".fn.g"):
-            out[name] = np.full(shape, REZERO_G, dtype=np.float32)
+            out[name] = np.full(shape, rezero_g, dtype=np.float32)
         elif ".block.1." in name:                      # GroupNorm affine
             if name.endswith("weight"):
                 out[name] = (1.0 + _uniform(seed, name, shape, 0.1)).astype(np.float32)
@@ -229,7 +230,7 @@ def synthetic_state_dict(cfg: DecoderConfig, seed: int = 0) -> "OrderedDict[str,
                 fan_in = int(np.prod(shape[1:]))
             out[name] = _uniform(seed, name, shape, 1.0 / np.sqrt(fan_in))
             if name.endswith("to_qkv.weight"):
-                out[name] = (out[name] * np.float32(QKV_SCALE)).astype(np.float32)
+                out[name] = (out[name] * np.float32(qkv_scale)).astype(np.float32)
         elif name.endswith(".bias"):
             wshape = param_shapes(cfg)[name[:-4] + "weight"]
             if name.endswith(".3.conv.bias") and len(wshape) == 4 and wshape[2] == 4:
