@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--frames", type=int, default=600, help="length of the reference utterance's mel")
     ap.add_argument("--segment", type=int, default=176, help="out_size: fix_len_compatibility(2*22050//256)")
     ap.add_argument("--check", type=int, default=0, help="compare the first K losses with the CPU oracle (slow)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=2, help="iterations of the CPU oracle (torch autograd + Adam) timed")
     ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
                     help="fused: HIP clip+Adam in 3 launches (unitspeech_amd.FusedAdam); torch: clip_grad_norm_ + torch.optim.Adam")
     a = ap.parse_args()
@@ -71,8 +73,46 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
+    eng = model._get_engine()
+    fwd_flops = eng.lib.us_estimator_flops(eng.handle, a.segment)          # direct-convolution count of SURVEY.md 8(d), one item
+    step_flops = 3.0 * fwd_flops                                           # forward + data gradients + weight gradients
+    achieved = step_flops / dt / 1e12
     res = {"metric": "fine-tune seconds/iteration (B=1, 176-frame crop, fwd+bwd+clip+Adam)", "value": dt, "unit": "s/iter",
-           "optimizer": a.optimizer, "iters": a.iters, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": loss.item()}
+           "higher_is_better": False, "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"finetune.py:131-165 inner loop, B=1, {a.segment}-frame crops of a {L}-frame utterance, full-size decoder, "
+                                  f"Adam lr 2e-5, clip 1.0", "optimizer": a.optimizer},
+           "iters": a.iters, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": loss.item(),
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                        "flops_per_iteration": step_flops,
+                        "flops_basis": "direct-form convolution FLOPs (3x the forward count of SURVEY.md 8(d)) over wall time of the whole "
+                                       "iteration incl. clip + Adam; the Winograd forward / data-gradient convolutions execute 16/36 of them"}}
+    if not a.no_cpu_baseline:
+        import os
+        from oracle import decoder_oracle as O
+        cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("UNITSPEECH_CPU_THREADS", "16")))
+        torch.set_num_threads(cores)
+        sdc = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+        optc = torch.optim.Adam(list(sdc.values()), lr=2e-5)
+        rs = random.Random(0)
+        gen = torch.Generator().manual_seed(0)
+        times = []
+        for i in range(a.cpu_baseline_iters + 1):                         # first iteration untimed (allocator / thread-pool warm-up)
+            t1 = time.perf_counter()
+            y_cut, m_cut, cond_y = O.fine_tune_segment(cond_x, y, y_mask, y_lengths, L, attn, a.segment, cfg.n_feats, rng=rs)
+            tt = torch.clamp(torch.rand(1, generator=gen), 1e-5, 1 - 1e-5)
+            zz = torch.randn(y_cut.shape, generator=gen)
+            lossc, _ = O.loss_t(sdc, y_cut, m_cut, cond_y, tt, spk, zz, cfg.n_feats)
+            optc.zero_grad()
+            lossc.backward()
+            torch.nn.utils.clip_grad_norm_(list(sdc.values()), 1)
+            optc.step()
+            if i > 0:
+                times.append(time.perf_counter() - t1)
+        cpu_dt = sum(times) / len(times)
+        model_name = next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.lower().startswith("model name")), "unknown")
+        res["cpu_baseline"] = {"value": cpu_dt, "unit": "s/iter", "cores": cores, "kind": "port", "cpu": model_name,
+                               "sample": f"{a.cpu_baseline_iters} iterations of the CPU oracle (torch autograd + clip + torch.optim.Adam) on the "
+                                         f"same crop shape, after one warm-up iteration"}
 
     if a.check > 0:
         # same python/torch draws replayed on the CPU oracle (fresh weights, same optimiser)

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from unitspeech_amd import DecoderConfig, FusedAdam, UnitSpeech, synthetic_state_dict
+from unitspeech_amd.checkpoint import build_decoder, infer_config, load_decoder_checkpoint, save_finetuned_checkpoint
 from unitspeech_amd.util import fix_len_compatibility, generate_path, sequence_mask
 
 
@@ -33,6 +34,8 @@ def main():
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--reference_root", type=str, default=None)
     ap.add_argument("--out_dir", type=str, default="checkpoints/inference")
+    ap.add_argument("--decoder_checkpoint", type=str, default=None,
+                    help="pre-trained decoder checkpoint to start from (train_STEP1.py:297-304 layout); --synthetic uses seeded weights otherwise")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     if not torch.cuda.is_available():
@@ -44,10 +47,17 @@ def main():
     cfg = DecoderConfig()
     n_down = len(cfg.dim_mults) - 1
     segment = fix_len_compatibility(2 * 22050 // 256, n_down)                 # out_size, finetune.py:40-44 (= 176)
-    decoder = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
+    base = None
+    if args.decoder_checkpoint:
+        base = load_decoder_checkpoint(args.decoder_checkpoint)                  # finetune.py:61-63
+        decoder = build_decoder(base)
+        cfg = infer_config(base.model)
+    else:
+        decoder = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
 
     if args.synthetic:
-        decoder.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, 0).items()})
+        if base is None:
+            decoder.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, 0).items()})
         g = np.random.Generator(np.random.Philox(key=args.ID & 0xffff))
         L = 600
         Lu = L // 3
@@ -88,8 +98,7 @@ def main():
     print(f"{args.n_iters} iterations in {dt:.2f} s ({1e3 * dt / max(args.n_iters, 1):.1f} ms/iter)")
     os.makedirs(args.out_dir, exist_ok=True)
     path = os.path.join(args.out_dir, f"{args.ID}.pt")
-    torch.save({"model": {k: v.detach().cpu() for k, v in decoder.state_dict().items()}, "spk_emb": spk_emb.cpu(), "mel_min": mel_min,
-                "mel_max": mel_max}, path)                                                   # finetune.py:167-173
+    save_finetuned_checkpoint(path, decoder, spk_emb, mel_min, mel_max, base=base)           # finetune.py:167-173
     print(f"saved {path}")
 
 

@@ -80,11 +80,15 @@ int us_estimator_forward(us_handle h, const float* x, const float* mask, const f
  * coef_host: optional HOST table [N][8] of per-step scalars (see us_step_coefficients); NULL = computed
  *        by the library.
  * micro_batch: utterances processed together (0 = library default); workspace must hold
- *        us_sampler_workspace_bytes(h, min(micro_batch, B), T, n_cfg). */
+ *        us_sampler_workspace_bytes(h, min(micro_batch, B), T, n_cfg).
+ * mel_range_host: NULL, or HOST {mel_min, mel_max}: the caller's next step, the mel de-normalisation
+ *        `(y + 1) / 2 * (mel_max - mel_min) + mel_min` (inference.py:140) that feeds the vocoder, is applied in the
+ *        sampler's last pass (same fp32 operation order), so `out` is the vocoder's input [B, n_feats, T]. */
 int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const float* cond, const float* spk,
                          const float* noise, uint64_t seed, int64_t utt_offset, int B, int T, int n_timesteps,
                          float text_gradient_scale, float spk_gradient_scale, const float* coef_host,
-                         int micro_batch, float* out, void* workspace, size_t workspace_bytes, us_stream stream);
+                         int micro_batch, const float* mel_range_host, float* out, void* workspace, size_t workspace_bytes,
+                         us_stream stream);
 
 /* Host helper: the per-step scalars the sampler update consumes, [N][8] fp32:
  * {sqrt_recip_acp, sqrt_recipm1_acp*sqrt_1m_acp, sqrt(acp_prev), sqrt(1-acp_prev-sigma^2), sqrt_1m_acp,
@@ -99,18 +103,70 @@ double us_estimator_flops(us_handle h, int T);
 
 /* ---- training (fine-tune) path: `loss_t` forward + `loss.backward()` through the score network -------------------
  * us_estimator_forward_train == us_estimator_forward, but every tensor the backward needs is kept inside `workspace`
- * (sized by us_train_workspace_bytes), which must stay untouched until us_estimator_backward has been enqueued.
- * us_estimator_backward(grad_out [B, n_feats, T]) writes d loss / d parameter for every `estimator.*` state_dict key
- * into the caller's buffers (reference layout and shape of that key; overwritten, not accumulated).  keys[i]/grads[i]
- * pair a key with its device buffer; all estimator keys must be present.  Input gradients are not produced (the
- * reference never needs them: finetune.py:131-165 optimises decoder parameters only). */
+ * (sized by us_train_workspace_bytes), which must stay untouched until us_estimator_backward has been enqueued or the
+ * tape has been released.  *tape_id names this forward's record; several may be live at once (each in its own
+ * workspace; beyond 16 the oldest is dropped).
+ * us_estimator_backward(tape_id, grad_out [B, n_feats, T]) writes d loss / d parameter for every `estimator.*` state_dict
+ * key into the caller's buffers (reference layout and shape of that key; overwritten, not accumulated).  keys[i]/grads[i]
+ * pair a key with its device buffer; all estimator keys must be present.  B, T must be the forward's.  Fails with
+ * US_EINVAL when tape_id is not live (consumed, released or evicted) -- a backward never runs on another forward's tape.
+ * grad_x, grad_mu [B, n_feats, T], grad_spk [B, spk_emb_dim]: optional (NULL = not wanted) gradients w.r.t. the inputs
+ * x, mu and spk_emb (the reference's trainers reach the text / unit encoder through them: train_STEP1.py:381,
+ * train_STEP2.py:299).  The tape is consumed by the call. */
 size_t us_train_workspace_bytes(us_handle h, int B, int T);
 int us_estimator_forward_train(us_handle h, const float* x, const float* mask, const float* mu, const float* t,
                                const float* spk, float* out, int B, int T, void* workspace, size_t workspace_bytes,
-                               us_stream stream);
+                               uint64_t* tape_id, us_stream stream);
 /* flags: bit 0 = the gradient buffers are already zero (e.g. views of one zero-filled blob): skips 228 fill launches. */
-int us_estimator_backward(us_handle h, const float* grad_out, const char* const* keys, float* const* grads, int n_grads,
-                          int flags, us_stream stream);
+int us_estimator_backward(us_handle h, uint64_t tape_id, const float* grad_out, int B, int T, const char* const* keys,
+                          float* const* grads, int n_grads, int flags, float* grad_x, float* grad_mu, float* grad_spk,
+                          us_stream stream);
+/* Drop a tape whose backward will never run (its workspace may then be reused). */
+int us_tape_release(us_handle h, uint64_t tape_id);
+
+/* ---- elementwise steps of the training objective (no handle) -------------------------------------------------------
+ * `forward_diffusion(x0, mask, t)` (unitspeech/unitspeech.py:376-384) with the gaussian draw z passed in:
+ *   xt = (x0 * exp(-c/2) + z * sqrt(1 - exp(-c))) * mask, z_masked = z * mask, c = beta_min*t + (beta_max-beta_min)/2*t^2.
+ *   z == NULL: xt = x0 * exp(-c/2) * mask only (the backward of xt w.r.t. x0, applied to a gradient).
+ * `loss_t`'s objective (:403-404): loss[0] = sum((score * sqrt(1 - exp(-c)) + z_masked)^2) / (sum(mask) * F); dscore
+ *   (optional) = d loss / d score.  scratch: us_diffusion_loss_scratch_bytes(B, F, T) bytes. */
+int us_forward_diffusion(const float* x0, const float* mask, const float* t, const float* z, float* xt, float* z_masked,
+                         int B, int F, int T, float beta_min, float beta_max, us_stream stream);
+size_t us_diffusion_loss_scratch_bytes(int B, int F, int T);
+int us_diffusion_loss(const float* score, const float* z_masked, const float* t, const float* mask, float* loss,
+                      float* dscore, int B, int F, int T, float beta_min, float beta_max, void* scratch,
+                      size_t scratch_bytes, us_stream stream);
+/* out[i] = x[i] * scalar_dev[0] (chain rule with a device-resident upstream gradient); out = x * mask[b][t] on [B,F,T]. */
+int us_scale(const float* x, const float* scalar_dev, float* out, size_t n, us_stream stream);
+int us_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, us_stream stream);
+/* `fine_tune`'s segment crop (:458-486).  cond_x [B,F,Lu], y [B,F,Ly], attn [B,Lu,Ly]; start/count: DEVICE int64 [B]
+ * (crop offset and number of valid frames min(y_length, segment_size) per item).  Writes y_cut, cond_y [B,F,segment_size]
+ * (cond_y = attn_cut^T cond_x, masked) and seg_mask [B,segment_size]. */
+int us_finetune_segment(const float* cond_x, const float* y, const float* attn, const int64_t* start, const int64_t* count,
+                        float* y_cut, float* cond_y, float* seg_mask, int B, int F, int Lu, int Ly, int segment_size,
+                        us_stream stream);
+
+/* ---- conditioning producer of `execute_text_to_speech` (:424-438; the text encoder and duration predictor stay the
+ * caller's modules) -----------------------------------------------------------------------------------------------------
+ * us_tts_durations: w_ceil[B,L] = ceil(exp(logw) * x_mask) * length_scale, y_lengths[B] (int64) = max(sum_l w_ceil, 1).
+ * us_tts_align: `generate_path` (unitspeech/util.py:27-40) + `attn^T cond_x` + `sequence_mask`: cond_y [B,F,Tp] (frame t
+ *   takes the column of the symbol whose duration interval contains t; zeros at t >= y_lengths[b]), y_mask [B,Tp]
+ *   (optional), attn [B,L,Tp] 0/1 (optional).  cond_x [B,F,L]. */
+int us_tts_durations(const float* logw, const float* x_mask, float* w_ceil, int64_t* y_lengths, int B, int L,
+                     float length_scale, us_stream stream);
+int us_tts_align(const float* cond_x, const float* w_ceil, const float* x_mask, const int64_t* y_lengths, float* cond_y,
+                 float* attn, float* y_mask, int B, int F, int L, int Tp, us_stream stream);
+
+/* ---- one building block of the score network on its own (parity tests against per-module reference outputs) ---------
+ * prefix: the module's state_dict prefix ("estimator.downs.1.1", "estimator.downs.1.2", "estimator.downs.1.3",
+ * "estimator.ups.1.3"); level: resolution level whose geometry (n_feats >> level) x (T >> level) the block runs at.
+ * x / out: pixel-major [B][H][W][C] (the library's internal activation layout), x already multiplied by the frame mask
+ * where the reference masks the operand; mask: full-resolution [B][T]; temb: [B][dim + spk_emb_dim] (ResnetBlock only).
+ * Output masking follows the library's producer-side convention (attention / Downsample / Upsample outputs are stored
+ * masked): pass an all-ones mask to obtain the reference module's raw output. */
+enum { US_DEBUG_BLOCK = 0, US_DEBUG_RESNET = 1, US_DEBUG_ATTENTION = 2, US_DEBUG_DOWN = 3, US_DEBUG_UP = 4 };
+int us_debug_block(us_handle h, int kind, const char* prefix, int level, const float* x, const float* mask,
+                   const float* temb, float* out, int B, int T, void* workspace, size_t workspace_bytes, us_stream stream);
 
 /* Sampled kernel timing for the roofline report.  When enabled, the middle evaluation of every
  * us_reverse_diffusion micro-batch (and every us_estimator_forward) brackets each implicit-GEMM convolution launch,

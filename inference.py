@@ -21,36 +21,8 @@ import numpy as np
 import torch
 
 from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_state_dict
-
-
-class SyntheticFrontEnd:
-    """Stand-ins with the reference's signatures: `text_encoder(phoneme, lengths) -> (cond_x, x, x_mask)`
-    (unitspeech/encoder.py:294) and `duration_predictor(x, x_mask, w=None, g=spk_emb, reverse=True) -> logw`
-    (unitspeech/duration_predictor.py:47)."""
-
-    def __init__(self, n_feats: int, device):
-        g = torch.Generator().manual_seed(1234)
-        self.table = torch.randn(512, n_feats, generator=g).to(device) * 0.5
-        self.device = device
-
-    def text_encoder(self, phoneme, phoneme_lengths):
-        x = self.table[phoneme % self.table.shape[0]].transpose(1, 2)            # [B, n_feats, L]
-        ar = torch.arange(phoneme.shape[1], device=self.device)
-        x_mask = (ar.unsqueeze(0) < phoneme_lengths.unsqueeze(1)).unsqueeze(1).float()
-        return x * x_mask, x, x_mask
-
-    def duration_predictor(self, x, x_mask, w=None, g=None, reverse=True):
-        # 3..8 frames per symbol, deterministic in the symbol embedding
-        frames = 3.0 + 5.0 * torch.sigmoid(x.mean(1, keepdim=True))
-        return torch.log(frames) * x_mask
-
-
-def text_to_ids(text: str, device):
-    ids = [0]
-    for ch in text.strip().lower():
-        ids += [1 + (ord(ch) % 200), 0]                    # interspersed blank, as `intersperse` does (unitspeech/util.py:62)
-    t = torch.LongTensor(ids).unsqueeze(0).to(device)
-    return t, torch.LongTensor([t.shape[-1]]).to(device)
+from unitspeech_amd.checkpoint import build_decoder, load_decoder_checkpoint
+from unitspeech_amd.frontend import SyntheticFrontEnd, text_to_ids
 
 
 def main():
@@ -73,15 +45,15 @@ def main():
     torch.manual_seed(args.seed)
     cfg = DecoderConfig()
     n_down = len(cfg.dim_mults) - 1
-    decoder = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
 
     if args.synthetic:
+        decoder = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
         decoder.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, 0).items()})
         decoder = decoder.to(device).eval()
         fe = SyntheticFrontEnd(cfg.n_feats, device)
         text_encoder, duration_predictor = fe.text_encoder, fe.duration_predictor
-        spk = torch.randn(1, 1, cfg.spk_emb_dim, generator=torch.Generator().manual_seed(args.ID & 0xffff)).to(device)
-        spk_emb = spk / spk.norm()
+        spk = np.random.Generator(np.random.Philox(key=args.ID & 0xffff)).standard_normal((1, 1, cfg.spk_emb_dim), dtype=np.float32)
+        spk_emb = torch.from_numpy(spk / np.linalg.norm(spk)).to(device)
         mel_min, mel_max = torch.tensor(-11.5, device=device), torch.tensor(2.0, device=device)
         phoneme, phoneme_lengths = text_to_ids(args.text, device)
         vocoder = None
@@ -98,10 +70,9 @@ def main():
         vocoder = get_vocoder(config_path=os.path.join(root, rcfg.vocoder.config_path), checkpoint=os.path.join(root, rcfg.vocoder.ckpt_path),
                               device=device)
         ck = os.path.join(root, rcfg.decoder.checkpoint if args.ID < 0 else f"{rcfg.finetune.finetuned_decoders_path}/{args.ID}.pt")
-        dd = torch.load(ck, map_location="cpu")                                            # inference.py:66-74
-        decoder.load_state_dict(dd["model"])
-        decoder = decoder.to(device).eval()
-        mel_max, mel_min, spk_emb = dd["mel_max"].to(device), dd["mel_min"].to(device), dd["spk_emb"].to(device)
+        dd = load_decoder_checkpoint(ck)                                                   # inference.py:66-74,107-108,124
+        decoder = build_decoder(dd, device).eval()
+        mel_max, mel_min, spk_emb = dd.mel_max.to(device), dd.mel_min.to(device), dd.speaker_embedding(max(args.ID, 0)).to(device)
         e = rcfg.encoder
         text_encoder = Encoder(n_vocab=len(symbols) + 1, n_feats=cfg.n_feats, n_channels=e.n_channels, filter_channels=e.filter_channels,
                                n_heads=e.n_heads, n_layers=e.n_layers, kernel_size=e.kernel_size, p_dropout=e.p_dropout,
@@ -119,14 +90,15 @@ def main():
 
     t0 = time.perf_counter()
     with torch.no_grad():
-        y_enc, y_dec, attn = decoder.execute_text_to_speech(
+        # the de-normalisation of inference.py:140 happens in the sampler's last pass: `mel` is the vocoder's input as it stands
+        y_enc, mel, attn = decoder.execute_text_to_speech(
             phoneme=phoneme, phoneme_lengths=phoneme_lengths, spk_emb=spk_emb, text_encoder=text_encoder,
             duration_predictor=duration_predictor, num_downsamplings_in_unet=n_down, diffusion_steps=args.diffusion_steps,
-            length_scale=args.length_scale, text_gradient_scale=args.text_gradient_scale, spk_gradient_scale=args.spk_gradient_scale)
-        mel = (y_dec + 1) / 2 * (mel_max - mel_min) + mel_min                              # inference.py:140
+            length_scale=args.length_scale, text_gradient_scale=args.text_gradient_scale, spk_gradient_scale=args.spk_gradient_scale,
+            mel_range=(float(mel_min), float(mel_max)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    frames = y_dec.shape[-1]
+    frames = mel.shape[-1]
     print(f"decoded {frames} mel frames in {dt:.3f} s ({frames / dt:.1f} frames/s, RTF {dt / (frames * 256 / 22050):.3f}), "
           f"{args.diffusion_steps} diffusion steps, finite={bool(torch.isfinite(mel).all())}")
     if vocoder is None:

@@ -362,3 +362,37 @@ def fine_tune_segment(cond_x: Tensor, y: Tensor, y_mask: Tensor, y_lengths: Tens
     cond_y = torch.matmul(attn_cut.transpose(1, 2).contiguous(), cond_x.transpose(1, 2).contiguous())
     cond_y = cond_y.transpose(1, 2).contiguous() * y_cut_mask
     return y_cut, y_cut_mask, cond_y
+
+
+# ---------------------------------------------------------------------------------------------
+# callers either side of the sampler: conditioning producer (§8(f2)) and mel de-normalisation (§8(f1))
+# ---------------------------------------------------------------------------------------------
+def align_conditioning(cond_x: Tensor, logw: Tensor, x_mask: Tensor, length_scale: float, num_downsamplings_in_unet: int):
+    """`execute_text_to_speech`, unitspeech/unitspeech.py:424-438: durations -> frame counts -> padded length ->
+    `generate_path` -> attn^T cond_x.  Returns (cond_y [B,F,T'], y_mask [B,1,T'], attn [B,1,L,T'], y_max_length)."""
+    w_ceil = torch.ceil(torch.exp(logw) * x_mask) * length_scale
+    y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+    y_max_length = int(y_lengths.max())
+    t_pad = fix_len_compatibility(y_max_length, num_downsamplings_in_unet)
+    y_mask = sequence_mask(y_lengths, t_pad).unsqueeze(1).to(x_mask.dtype)
+    attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
+    attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
+    cond_y = torch.matmul(attn.squeeze(1).transpose(1, 2).contiguous(), cond_x.transpose(1, 2).contiguous())
+    return cond_y.transpose(1, 2).contiguous(), y_mask, attn, y_max_length
+
+
+def execute_text_to_speech(sd: Mapping[str, Tensor], phoneme: Tensor, phoneme_lengths: Tensor, spk_emb: Tensor, text_encoder,
+                           duration_predictor, num_downsamplings_in_unet: int, n_timesteps: int, length_scale: float, w_text: float,
+                           w_spk: float, z: Tensor, noise: Tensor, pe_scale: float = 1000.0):
+    """`execute_text_to_speech`, unitspeech/unitspeech.py:413-450 with the two gaussian sources (z, :441; per-step noise, :367)
+    supplied.  The crop of the returned path acts on the symbol axis of the 4-D tensor, as in the reference (:450)."""
+    cond_x, x, x_mask = text_encoder(phoneme, phoneme_lengths)
+    logw = duration_predictor(x, x_mask, w=None, g=spk_emb, reverse=True)
+    cond_y, y_mask, attn, n = align_conditioning(cond_x, logw, x_mask, length_scale, num_downsamplings_in_unet)
+    dec = reverse_diffusion(sd, z, y_mask, cond_y, spk_emb, n_timesteps, w_text, w_spk, noise=noise, pe_scale=pe_scale)
+    return cond_y[:, :, :n], dec[:, :, :n], attn[:, :, :n]
+
+
+def denormalize_mel(y: Tensor, mel_min: Tensor, mel_max: Tensor) -> Tensor:
+    """inference.py:140: the decoder's [-1, 1] output back to log-mel, the vocoder's input (:141)."""
+    return (y + 1) / 2 * (mel_max - mel_min) + mel_min

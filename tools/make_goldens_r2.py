@@ -147,11 +147,13 @@ def g_ckpt(U):
     m = build(U, CK, 3)
     spk = tt(synthetic_inputs(CK, 1, 8, seed=9))["spk_emb"]
     # train_STEP1.py:297-304 (decoder checkpoint written by the trainer)
-    torch.save({"model": m.state_dict(), "spk_emb": torch.zeros(4, 1, CK.spk_emb_dim), "mel_min": torch.tensor(-11.5),
+    table = torch.nn.Embedding.from_pretrained(torch.arange(4 * CK.spk_emb_dim, dtype=torch.float32).reshape(4, -1) / 1024)   # :133
+    torch.save({"model": m.state_dict(), "spk_emb": table.state_dict(), "mel_min": torch.tensor(-11.5),
                 "mel_max": torch.tensor(2.0), "iteration": 1234}, os.path.join(OUT, "ckpt_pretrained_small.pt"))
     # finetune.py:169-173 (speaker-adapted checkpoint)
-    torch.save({"model": m.state_dict(), "mel_min": torch.tensor(-11.5), "mel_max": torch.tensor(2.0), "spk_emb": spk},
-               os.path.join(OUT, "ckpt_finetuned_small.pt"))
+    d = torch.load(os.path.join(OUT, "ckpt_pretrained_small.pt"))        # finetune.py:62 loads the pre-trained dict and mutates it
+    d["model"] = m.state_dict(); d["mel_min"] = torch.tensor(-11.5); d["mel_max"] = torch.tensor(2.0); d["spk_emb"] = spk
+    torch.save(d, os.path.join(OUT, "ckpt_finetuned_small.pt"))
     for f in ("ckpt_pretrained_small.pt", "ckpt_finetuned_small.pt"):
         print(f"   wrote {f} ({os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB)")
 

@@ -32,13 +32,26 @@ SIGNATURES = {
     "us_estimator_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "us_reverse_diffusion": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                                                           C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
-                                                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+                                                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "us_step_coefficients": (C.c_int, [C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float)]),
     "us_fill_normal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
     "us_estimator_flops": (C.c_double, [C.c_void_p, C.c_int]),
     "us_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
-    "us_estimator_forward_train": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "us_estimator_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    "us_estimator_forward_train": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                                               C.POINTER(C.c_uint64), C.c_void_p]),
+    "us_estimator_backward": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
+                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "us_tape_release": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "us_forward_diffusion": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "us_diffusion_loss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "us_diffusion_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "us_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "us_mul_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "us_finetune_segment": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p]),
+    "us_tts_durations": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "us_tts_align": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
+    "us_debug_block": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     "us_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "us_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
@@ -52,14 +65,19 @@ _lib = None
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:
-    """dlopen the in-tree library (building it first when absent or stale)."""
+    """dlopen the in-tree library, building it first when absent or older than any of its sources (a cheap mtime check; with
+    no hipcc on the machine an existing library is used as it is)."""
     global _lib
     with _lock:
         if _lib is not None:
             return _lib
         path = _build.LIB
-        if build_if_missing and (not os.path.exists(path) or os.environ.get("UNITSPEECH_AMD_REBUILD") == "1"):
-            path = _build.build_library()
+        if build_if_missing:
+            try:
+                path = _build.build_library(force=os.environ.get("UNITSPEECH_AMD_REBUILD") == "1")
+            except RuntimeError:
+                if not os.path.exists(path) or _build.have_hipcc():
+                    raise
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not found and could not be built: the HIP decoder has no CPU fallback")
         lib = C.CDLL(path)

@@ -76,6 +76,10 @@ int pick_bk(int cin) { return (cin % 32 == 0) ? 32 : 16; }
 
 }  // namespace
 
+namespace us {
+void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+}
+
 struct us_decoder {
   us_config cfg{};
   int device = 0;
@@ -99,7 +103,11 @@ struct us_decoder {
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
   int wino_min_level = 0;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
-  std::shared_ptr<void> tape; // saved-activation record of the last us_estimator_forward_train call
+  // saved-activation records of us_estimator_forward_train calls that have not been consumed by a backward yet, by tape id
+  // (each lives in its caller's workspace; the oldest is dropped beyond kMaxTapes)
+  std::map<uint64_t, std::shared_ptr<void>> tapes;
+  uint64_t tape_serial = 0;
+  static constexpr size_t kMaxTapes = 16;
   std::string err;
 
   // ---- sampled kernel timing (bench.py roofline leg) ----
@@ -1032,7 +1040,8 @@ int us_step_coefficients(int N, float beta_min, float beta_max, float* coef) {
 
 int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const float* cond, const float* spk, const float* noise,
                          uint64_t seed, int64_t utt_offset, int B, int T, int N, float w_text, float w_spk, const float* coef_host,
-                         int micro_batch, float* out, void* workspace, size_t workspace_bytes, us_stream stream) {
+                         int micro_batch, const float* mel_range_host, float* out, void* workspace, size_t workspace_bytes,
+                         us_stream stream) {
   if (!h || !z || !mask || !cond || !spk || !out || !workspace) { g_last_error = "null argument"; return US_EINVAL; }
   if (N < 1) return h->fail(US_EINVAL, "n_timesteps must be >= 1");
   int rc = check_ready(h);
@@ -1117,7 +1126,8 @@ int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const f
       sa.seed = seed; sa.utt0 = utt_offset + b0; sa.step = i;
       US_HIP(h, launch_sampler_update(sa, s));
     }
-    US_HIP(h, launch_mul_mask(xt, mask_b, out + (size_t)b0 * FT, mb, F, T, s));       // :373
+    // :373 `xt * mask`, with the caller's mel de-normalisation (inference.py:140) folded into the same pass when asked for
+    US_HIP(h, launch_finish_mel(xt, mask_b, out + (size_t)b0 * FT, mb, F, T, mel_range_host, s));
   }
   return US_OK;
 }
@@ -1193,6 +1203,79 @@ int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* c
 }
 
 #include "train_abi.inc"
+
+// ---- one building block on its own (parity tests against the reference's per-module outputs) ------------------------------
+int us_debug_block(us_handle h, int kind, const char* prefix, int level, const float* x, const float* mask, const float* temb, float* out,
+                   int B, int T, void* workspace, size_t workspace_bytes, us_stream stream) {
+  if (!h || !prefix || !x || !mask || !out || !workspace) { g_last_error = "null argument"; return US_EINVAL; }
+  int rc = check_ready(h);
+  if (rc) return rc;
+  rc = check_shape(h, B, T);
+  if (rc) return rc;
+  if (level < 0 || level >= h->cfg.n_mults) return h->fail(US_EINVAL, "level %d out of range", level);
+  if (workspace_bytes < us_workspace_bytes(h, B, T)) return h->fail(US_EWORKSPACE, "workspace too small");
+  const std::string p(prefix);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Arena A(workspace, workspace_bytes);
+  Buffers b;
+  plan(h, A, B, T, b);
+  EvalCtx e{h, s, &b, B, T, mask, B};
+  US_HIP(h, hipMemsetAsync(b.stats, 0, b.stats_count * sizeof(double), s));
+  std::vector<const ResnetW*> rs;
+  std::vector<const AttnW*> as;
+  for (auto& d : h->downs) { rs.push_back(&d.r1); rs.push_back(&d.r2); as.push_back(&d.a); }
+  rs.push_back(&h->mid1); rs.push_back(&h->mid2); as.push_back(&h->mid_attn);
+  for (auto& u : h->ups) { rs.push_back(&u.r1); rs.push_back(&u.r2); as.push_back(&u.a); }
+  if (kind == US_DEBUG_BLOCK || kind == US_DEBUG_RESNET) {
+    for (const ResnetW* r0 : rs) {
+      if (r0->mlp_w->key != p + ".mlp.1.weight") continue;
+      if (r0->first) return h->fail(US_EINVAL, "the 2-channel first block has no stand-alone entry");
+      ResnetW r = *r0;
+      r.level = level;                   // geometry (H, W, mask stride) of the requested level; the weights are the module's own
+      if (kind == US_DEBUG_BLOCK) {      // Block = block1 of that ResnetBlock: Mish(GroupNorm(conv(x))) * mask, x pre-masked (:46-55)
+        double* st = next_stats(e);
+        US_HIP(h, conv3x3(e, r.c1, x, r.cin, level, b.S1[level], r.cout, st));
+        US_HIP(h, gn_apply(e, b.S1[level], level, r.cout, st, r.g1, r.b1, nullptr, nullptr, 0, false, false, out, r.cout));
+        return US_OK;
+      }
+      if (!temb) return h->fail(US_EINVAL, "ResnetBlock needs temb");
+      const int td = h->cfg.dim + h->cfg.spk_emb_dim;
+      US_HIP(h, launch_linear(temb, td, r.mlp_w->buf.p, r.mlp_b->buf.p, b.tproj + b.tproj_off[r.index], r.cout, B, td, r.cout, true, s));
+      US_HIP(h, resnet(e, r, x, r.cin, out, r.cout, false));
+      return US_OK;
+    }
+    return h->fail(US_ENOKEY, "no ResnetBlock '%s'", prefix);
+  }
+  if (kind == US_DEBUG_ATTENTION) {
+    for (const AttnW* a0 : as) {
+      if (a0->g->key != p + ".fn.g") continue;
+      AttnW a = *a0;
+      a.level = level;
+      US_HIP(h, attention(e, a, x, a.dim, out, a.dim));
+      return US_OK;
+    }
+    return h->fail(US_ENOKEY, "no attention '%s'", prefix);
+  }
+  if (kind == US_DEBUG_DOWN) {
+    for (auto& d : h->downs)
+      if (d.has_ds && d.ds.conv.w->key == p + ".conv.weight") {
+        if (level + 1 >= h->cfg.n_mults) return h->fail(US_EINVAL, "no level below %d", level);
+        US_HIP(h, conv_down(e, d.ds.conv, x, d.ds.dim, level, out, d.ds.dim));
+        return US_OK;
+      }
+    return h->fail(US_ENOKEY, "no Downsample '%s'", prefix);
+  }
+  if (kind == US_DEBUG_UP) {
+    for (auto& u : h->ups)
+      if (u.us.conv.w->key == p + ".conv.weight") {
+        if (level < 1) return h->fail(US_EINVAL, "no level above 0");
+        US_HIP(h, conv_up(e, u.us.conv, x, u.us.dim, level, out, u.us.dim));
+        return US_OK;
+      }
+    return h->fail(US_ENOKEY, "no Upsample '%s'", prefix);
+  }
+  return h->fail(US_EINVAL, "unknown block kind %d", kind);
+}
 
 const char* us_last_error(us_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 

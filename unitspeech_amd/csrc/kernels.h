@@ -8,6 +8,24 @@
 
 namespace us {
 
+// Correctly rounded single operations that the compiler may NOT contract into an fma.  hipcc compiles with -ffp-contract=fast and
+// HIP's __fmul_rn / __fadd_rn are plain operators to it (a `__fadd_rn(__fmul_rn(a, b), c)` becomes one v_fma_f32), so expressions
+// that must round like the reference's separate tensor ops (sampler update, forward diffusion, mel de-normalisation) use these.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+#endif
+
 constexpr int kHeads = 4;       // unitspeech/unitspeech.py:79
 constexpr int kDimHead = 32;    // unitspeech/unitspeech.py:79
 constexpr int kHidden = kHeads * kDimHead;
@@ -143,6 +161,14 @@ struct SamplerArgs {
 };
 hipError_t launch_sampler_update(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, hipStream_t s);
+// out = x * mask, then (mel_range_host != null) the de-normalisation (v + 1) / 2 * (max - min) + min of inference.py:140;
+// mel_range_host = {mel_min, mel_max} on the host
+hipError_t launch_finish_mel(const float* x, const float* mask, float* out, int B, int F, int T, const float* mel_range_host, hipStream_t s);
+// data gradient of the 2-channel first ResnetBlock back to the planar inputs (glue.hip); gmu / gx: [B][F][T] or null
+hipError_t launch_first_conv_dgrad(const float* gy, const float* gr, const float* w3, const float* w1, const float* mask, float* gmu,
+                                   float* gx, int B, int F, int T, int C, hipStream_t s);
+// thread-local "last error" text of the library (decoder.hip), for entry points that have no handle
+void set_last_error(const char* msg);
 hipError_t launch_fill_normal(float* out, size_t n, unsigned long long seed, unsigned long long key, hipStream_t s);
 
 // ---- backward pass (train.hip) ---------------------------------------------------------------------------

@@ -433,7 +433,7 @@ hipError_t launch_fill_normal(float* out, size_t n, unsigned long long seed, uns
 
 // ---------------------------------------------------------------------------------------------------
 // CFG combine + ancestral update.  Operation order follows the reference's tensor expressions so that an
-// identical score gives a bit-identical update (no FMA contraction: explicit __fmul_rn/__fadd_rn).
+// identical score gives a bit-identical update (no FMA contraction: explicit mul_rn/add_rn).
 //   score = s + w_t*(s - s_tu) + w_s*(s - s_su)                                   (unitspeech.py:322-324)
 //   x0    = c0*xt + c1*score                                                      (:273-278)
 //   mean  = c2*x0 - (c3*score)*c4                                                 (:283-287)
@@ -457,14 +457,14 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(SamplerArgs a) {
       f32x4 s = *reinterpret_cast<const f32x4*>(a.score + 2 * BFT + i0);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        sc[k] = __fadd_rn(__fadd_rn(s[k], __fmul_rn(a.w_text, __fsub_rn(s[k], s_tu[k]))),
-                          __fmul_rn(a.w_spk, __fsub_rn(s[k], s_su[k])));
+        sc[k] = add_rn(add_rn(s[k], mul_rn(a.w_text, sub_rn(s[k], s_tu[k]))),
+                          mul_rn(a.w_spk, sub_rn(s[k], s_su[k])));
     } else if (a.mode == 2 || a.mode == 1) {
       f32x4 s_u = *reinterpret_cast<const f32x4*>(a.score + i0);
       f32x4 s = *reinterpret_cast<const f32x4*>(a.score + BFT + i0);
       const float w = a.mode == 2 ? a.w_text : a.w_spk;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) sc[k] = __fadd_rn(s[k], __fmul_rn(w, __fsub_rn(s[k], s_u[k])));
+      for (int k = 0; k < 4; ++k) sc[k] = add_rn(s[k], mul_rn(w, sub_rn(s[k], s_u[k])));
     } else {
       sc = *reinterpret_cast<const f32x4*>(a.score + i0);
     }
@@ -481,9 +481,9 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(SamplerArgs a) {
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float x0 = __fadd_rn(__fmul_rn(a.c0, x[k]), __fmul_rn(a.c1, sc[k]));
-      float mean = __fsub_rn(__fmul_rn(a.c2, x0), __fmul_rn(__fmul_rn(a.c3, sc[k]), a.c4));
-      o[k] = __fmul_rn(__fadd_rn(mean, __fmul_rn(a.c5, nz[k])), m[k]);
+      float x0 = add_rn(mul_rn(a.c0, x[k]), mul_rn(a.c1, sc[k]));
+      float mean = sub_rn(mul_rn(a.c2, x0), mul_rn(mul_rn(a.c3, sc[k]), a.c4));
+      o[k] = mul_rn(add_rn(mean, mul_rn(a.c5, nz[k])), m[k]);
     }
     *reinterpret_cast<f32x4*>(a.out + i0) = o;
   }

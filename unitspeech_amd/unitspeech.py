@@ -180,6 +180,15 @@ class _Engine:
                 self.versions[key] = tag
                 del src   # stream-ordered: the caching allocator keeps the block alive for queued work on this stream
 
+    def invalidate(self, keys=None):
+        """Forget what has been uploaded (all keys, or the given ones): the next call re-packs them.  Needed after in-place
+        writes that do not bump `tensor._version` (`p.data.copy_()`, `p.data.mul_()`: EMA / clamp idioms)."""
+        if keys is None:
+            self.versions.clear()
+        else:
+            for k in keys:
+                self.versions.pop(k, None)
+
     def get_workspace(self, nbytes: int, device) -> torch.Tensor:
         if self.workspace is None or self.workspace.numel() < nbytes or self.workspace.device != device:
             self.workspace = None
@@ -187,22 +196,42 @@ class _Engine:
         return self.workspace
 
 
+class _TapeRef:
+    """Releases a forward_train tape that never saw its backward (the graph was dropped)."""
+
+    def __init__(self, eng, tape_id):
+        self.eng, self.tape_id, self.live = eng, tape_id, True
+
+    def __del__(self):
+        try:
+            if self.live and self.eng.handle:
+                self.eng.lib.us_tape_release(self.eng.handle, C.c_uint64(self.tape_id))
+        except Exception:
+            pass
+
+
 class _EstimatorFn(torch.autograd.Function):
-    """autograd bridge: forward = us_estimator_forward_train (activations stay in the workspace), backward =
-    us_estimator_backward, which returns d loss / d parameter for every estimator tensor."""
+    """autograd bridge: forward = us_estimator_forward_train (activations stay in this call's own workspace, named by a tape
+    id), backward = us_estimator_backward on THAT tape: d loss / d parameter for every estimator tensor and, where asked for,
+    d loss / d x, d mu, d spk_emb (the reference's trainers reach their encoders through mu: train_STEP1.py:381,
+    train_STEP2.py:299)."""
 
     @staticmethod
     def forward(ctx, est, eng, x, mask, mu, t, spk, keys, *params):
         B, F, T = x.shape
         dev = x.device
         out = torch.empty_like(x)
+        tape = C.c_uint64(0)
         with torch.cuda.device(dev):
             nbytes = eng.lib.us_train_workspace_bytes(eng.handle, B, T)
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
             rc = eng.lib.us_estimator_forward_train(eng.handle, _dev_ptr(x), _dev_ptr(mask), _dev_ptr(mu), _dev_ptr(t), _dev_ptr(spk),
-                                                    _dev_ptr(out), B, T, _dev_ptr(ws), ws.numel(), _stream())
+                                                    _dev_ptr(out), B, T, _dev_ptr(ws), ws.numel(), C.byref(tape), _stream())
         _lib.check(rc, eng.handle, "us_estimator_forward_train")
         ctx.eng, ctx.ws, ctx.keys, ctx.dev = eng, ws, keys, dev
+        ctx.tape = _TapeRef(eng, tape.value)
+        ctx.shape = (B, F, T)
+        ctx.spk_shape = tuple(spk.shape)
         ctx.inputs = (x, mask, mu, t, spk)      # keep the operands alive until backward has been enqueued
         ctx.param_meta = [(p.shape, p.dtype) for p in params]
         return out
@@ -210,6 +239,7 @@ class _EstimatorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         eng, keys, dev = ctx.eng, ctx.keys, ctx.dev
+        B, F, T = ctx.shape
         g = _f32c(grad_out, dev)
         # one zero-filled blob, one view per parameter: a single fill instead of one per tensor
         sizes = [int(torch.Size(shape).numel()) for shape, _ in ctx.param_meta]
@@ -222,13 +252,109 @@ class _EstimatorFn(torch.autograd.Function):
         n = len(keys)
         ckeys = (C.c_char_p * n)(*[k.encode() for k in keys])
         cptrs = (C.c_void_p * n)(*[gr.data_ptr() for gr in grads])
+        need_x, _, need_mu, _, need_spk = ctx.needs_input_grad[2:7]
+        gx = torch.empty(B, F, T, dtype=torch.float32, device=dev) if need_x else None
+        gmu = torch.empty(B, F, T, dtype=torch.float32, device=dev) if need_mu else None
+        gspk = torch.empty(ctx.spk_shape, dtype=torch.float32, device=dev) if need_spk else None
+        opt = lambda v: _dev_ptr(v) if v is not None else None
         with torch.cuda.device(dev):
-            rc = eng.lib.us_estimator_backward(eng.handle, _dev_ptr(g), ckeys, cptrs, n, 1, _stream())
+            rc = eng.lib.us_estimator_backward(eng.handle, C.c_uint64(ctx.tape.tape_id), _dev_ptr(g), B, T, ckeys, cptrs, n, 1,
+                                               opt(gx), opt(gmu), opt(gspk), _stream())
+        ctx.tape.live = False                   # consumed (or refused) by the library either way
         _lib.check(rc, eng.handle, "us_estimator_backward")
         ctx.ws = None
         ctx.inputs = None
         eng.last_grad_blob = blob               # data-parallel training all-reduces this one buffer (sharding.allreduce_gradients)
-        return (None, None, None, None, None, None, None, None, *[gr.to(dt) for gr, (_, dt) in zip(grads, ctx.param_meta)])
+        return (None, None, gx, None, gmu, None, gspk, None, *[gr.to(dt) for gr, (_, dt) in zip(grads, ctx.param_meta)])
+
+
+class _ForwardDiffusionFn(torch.autograd.Function):
+    """`forward_diffusion` (unitspeech/unitspeech.py:376-384) on the HIP library; z is the caller's gaussian draw."""
+
+    @staticmethod
+    def forward(ctx, lib, x0, mask, t, z, beta_min, beta_max):
+        B, F, T = x0.shape
+        xt, zm = torch.empty_like(x0), torch.empty_like(x0)
+        with torch.cuda.device(x0.device):
+            rc = lib.us_forward_diffusion(_dev_ptr(x0), _dev_ptr(mask), _dev_ptr(t), _dev_ptr(z), _dev_ptr(xt), _dev_ptr(zm), B, F, T,
+                                          beta_min, beta_max, _stream())
+        _lib.check(rc, None, "us_forward_diffusion")
+        ctx.lib, ctx.betas = lib, (beta_min, beta_max)
+        ctx.save_for_backward(mask, t)
+        ctx.mark_non_differentiable(zm)
+        return xt, zm
+
+    @staticmethod
+    def backward(ctx, g_xt, _g_zm):
+        mask, t = ctx.saved_tensors
+        g = _f32c(g_xt, g_xt.device)
+        B, F, T = g.shape
+        out = torch.empty_like(g)
+        with torch.cuda.device(g.device):      # d xt / d x0 = exp(-c/2) * mask: the same kernel without the noise term
+            rc = ctx.lib.us_forward_diffusion(_dev_ptr(g), _dev_ptr(mask), _dev_ptr(t), None, _dev_ptr(out), None, B, F, T,
+                                              ctx.betas[0], ctx.betas[1], _stream())
+        _lib.check(rc, None, "us_forward_diffusion (backward)")
+        return None, out, None, None, None, None, None
+
+
+class _MulMaskFn(torch.autograd.Function):
+    """`cond * mask` (:400) on [B, F, T]."""
+
+    @staticmethod
+    def forward(ctx, lib, x, mask):
+        B, F, T = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = lib.us_mul_mask(_dev_ptr(x), _dev_ptr(mask), _dev_ptr(out), B, F, T, _stream())
+        _lib.check(rc, None, "us_mul_mask")
+        ctx.lib = lib
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return None, _MulMaskFn.apply(ctx.lib, _f32c(g, g.device), mask), None
+
+
+class _DiffusionLossFn(torch.autograd.Function):
+    """Score-matching objective of `loss_t` (:403-404) with its gradient w.r.t. the score, one fused pass."""
+
+    @staticmethod
+    def forward(ctx, lib, score, zm, t, mask, beta_min, beta_max):
+        B, F, T = score.shape
+        dev = score.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dscore = torch.empty_like(score)
+        nb = int(lib.us_diffusion_loss_scratch_bytes(B, F, T))
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.us_diffusion_loss(_dev_ptr(score), _dev_ptr(zm), _dev_ptr(t), _dev_ptr(mask), _dev_ptr(loss), _dev_ptr(dscore), B, F, T,
+                                       beta_min, beta_max, _dev_ptr(scratch), nb, _stream())
+        _lib.check(rc, None, "us_diffusion_loss")
+        ctx.lib = lib
+        ctx.save_for_backward(dscore)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dscore,) = ctx.saved_tensors
+        out = torch.empty_like(dscore)
+        gs = _f32c(g.reshape(1), dscore.device)
+        with torch.cuda.device(dscore.device):
+            rc = ctx.lib.us_scale(_dev_ptr(dscore), _dev_ptr(gs), _dev_ptr(out), dscore.numel(), _stream())
+        _lib.check(rc, None, "us_scale")
+        return None, out, None, None, None, None, None
+
+
+def _check_shapes(B, F, T, S, **tensors):
+    """Raise before the C ABI sees a pointer whose extent does not match (it takes raw device pointers and never broadcasts)."""
+    want = {"x": (B, F, T), "z": (B, F, T), "mu": (B, F, T), "cond": (B, F, T), "mask": (B, 1, T), "spk_emb": (B, 1, S), "t": (B,)}
+    for name, v in tensors.items():
+        if v is None:
+            continue
+        if tuple(v.shape) != want[name]:
+            raise ValueError(f"{name} must have shape {want[name]}, got {tuple(v.shape)}")
 
 
 class GradLogPEstimator2d(BaseModule):
@@ -292,7 +418,12 @@ class GradLogPEstimator2d(BaseModule):
         if spk_emb is None:
             raise ValueError("spk_emb is required (the reference squeezes it unconditionally, unitspeech.py:168)")
         dev = x.device
+        if x.dim() != 3:
+            raise ValueError(f"x must be [B, n_feats, T], got {tuple(x.shape)}")
         B, F, T = x.shape
+        if self._owner is not None and F != self._owner.n_feats:
+            raise ValueError(f"x has {F} mel bins, the decoder was built for n_feats={self._owner.n_feats}")
+        _check_shapes(B, F, T, self.spk_emb_dim, mu=mu, mask=mask, spk_emb=spk_emb, t=t)
         eng = self._get_engine(F)
         weights = list(self._named_weights())
         if self._owner is None:
@@ -302,12 +433,12 @@ class GradLogPEstimator2d(BaseModule):
             weights += self._owner._own_weights()
         eng.sync_weights(weights, dev)
         x, mu, mask, t, spk = (_f32c(v, dev) for v in (x, mu, mask, t, spk_emb))
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training step (`loss_t` under autograd, unitspeech.py:393-405): parameters only; the reference never
-            # differentiates w.r.t. x / mu / spk_emb on this path
+        wants_grad = any(p.requires_grad for p in self.parameters()) or any(v.requires_grad for v in (x, mu, spk))
+        if torch.is_grad_enabled() and wants_grad:
+            # training step (`loss_t` under autograd, unitspeech.py:393-405): gradients for the parameters and for x / mu /
+            # spk_emb (a frozen decoder still passes d loss / d mu on to the caller's encoder, train_STEP2.py:130-131,299)
             named = list(self._named_weights())
-            return _EstimatorFn.apply(self, eng, x.detach(), mask.detach(), mu.detach(), t.detach(), spk.detach(),
-                                      [k for k, _ in named], *[p for _, p in named])
+            return _EstimatorFn.apply(self, eng, x, mask.detach(), mu, t.detach(), spk, [k for k, _ in named], *[p for _, p in named])
         out = torch.empty_like(x)
         with torch.cuda.device(dev):
             nbytes = eng.lib.us_workspace_bytes(eng.handle, B, T)
@@ -357,6 +488,13 @@ class UnitSpeech(BaseModule):
     def _own_weights(self):
         return [("text_uncon", self.text_uncon), ("spk_uncon", self.spk_uncon)]
 
+    def invalidate_weights(self, keys=None):
+        """Tell the engine that parameter storage was written in place behind autograd's back (`p.data.copy_()`, `p.data.mul_()`,
+        EMA / clamp idioms do not bump `p._version`, which is what the upload cache is keyed on): the next call re-uploads
+        everything (or the given state_dict keys)."""
+        if self._engine_obj is not None:
+            self._engine_obj.invalidate(keys)
+
     def _sync(self, device):
         eng = self._get_engine()
         eng.sync_weights(list(self.estimator._named_weights()) + self._own_weights(), device)
@@ -400,16 +538,22 @@ class UnitSpeech(BaseModule):
     # -- sampling ----------------------------------------------------------------------------------
     @torch.no_grad()
     def reverse_diffusion(self, z, mask, cond, spk_emb, n_timesteps, text_gradient_scale=0.0, spk_gradient_scale=0.0, *,
-                          noise: Optional[torch.Tensor] = None, rng: str = "torch", seed: int = 0, utt_offset: int = 0):
+                          noise: Optional[torch.Tensor] = None, rng: str = "torch", seed: int = 0, utt_offset: int = 0,
+                          mel_range=None):
         """`reverse_diffusion`, unitspeech/unitspeech.py:333-374.
 
         Extra keyword-only arguments (the reference draws `torch.randn` inside the loop, :367):
           noise  explicit [N, B, n_feats, T] gaussian draws (parity tests);
           rng    "torch": pre-draw the N tensors with `torch.randn` in the reference's order (default);
-                 "philox": generate in-kernel from (seed, utt_offset + item, step), independent of sharding.
+                 "philox": generate in-kernel from (seed, utt_offset + item, step), independent of sharding;
+          mel_range  (mel_min, mel_max): return the de-normalised mel `(y + 1) / 2 * (mel_max - mel_min) + mel_min`, i.e. the
+                 vocoder's input (inference.py:140-141), computed in the sampler's last pass instead of by the caller.
         Every item gets the B=1 schedule (the reference is only valid for B=1)."""
         dev = z.device
+        if z.dim() != 3 or z.shape[1] != self.n_feats:
+            raise ValueError(f"z must be [B, {self.n_feats}, T], got {tuple(z.shape)}")
         B, F, T = z.shape
+        _check_shapes(B, F, T, self.spk_uncon.shape[-1], cond=cond, mask=mask, spk_emb=spk_emb)
         N = int(n_timesteps)
         eng = self._sync(dev)
         z, mask, cond, spk = (_f32c(v, dev) for v in (z, mask, cond, spk_emb))
@@ -427,6 +571,7 @@ class UnitSpeech(BaseModule):
         n_cfg = 1 + (wt > 0.0) + (ws_ > 0.0)
         out = torch.empty_like(z)
         coef = self._step_coefficients(N)
+        mel = (C.c_float * 2)(float(mel_range[0]), float(mel_range[1])) if mel_range is not None else None
         with torch.cuda.device(dev):
             mb = self.micro_batch if self.micro_batch > 0 else 8
             mb = min(mb, B)
@@ -435,7 +580,7 @@ class UnitSpeech(BaseModule):
             rc = eng.lib.us_reverse_diffusion(
                 eng.handle, _dev_ptr(z), _dev_ptr(mask), _dev_ptr(cond), _dev_ptr(spk),
                 _dev_ptr(noise) if noise is not None else None, C.c_uint64(seed), C.c_int64(utt_offset), B, T, N, wt, ws_,
-                C.c_void_p(coef.data_ptr()), mb, _dev_ptr(out), _dev_ptr(wsb), wsb.numel(), _stream())
+                C.c_void_p(coef.data_ptr()), mb, mel, _dev_ptr(out), _dev_ptr(wsb), wsb.numel(), _stream())
         _lib.check(rc, eng.handle, "us_reverse_diffusion")
         return out
 
@@ -447,77 +592,94 @@ class UnitSpeech(BaseModule):
 
     # -- training-side -----------------------------------------------------------------------------
     def forward_diffusion(self, x0, mask, t):
-        """`forward_diffusion`, unitspeech/unitspeech.py:376-384 (elementwise host glue on device tensors)."""
-        time = t.unsqueeze(-1).unsqueeze(-1)
-        cum_noise = get_noise(time, self.beta_min, self.beta_max, cumulative=True)
-        mean = x0 * torch.exp(-0.5 * cum_noise)
-        variance = 1.0 - torch.exp(-cum_noise)
-        z = torch.randn(x0.shape, dtype=x0.dtype, device=x0.device, requires_grad=False)
-        xt = mean + z * torch.sqrt(variance)
-        return xt * mask, z * mask
+        """`forward_diffusion`, unitspeech/unitspeech.py:376-384: one HIP pass; the gaussian draw is torch's, in the reference's
+        RNG order.  Returns (xt * mask, z * mask)."""
+        dev = x0.device
+        if dev.type != "cuda":
+            raise RuntimeError("the HIP decoder needs tensors on a ROCm device (no CPU fallback); got " + str(dev))
+        z = torch.randn(x0.shape, dtype=x0.dtype, device=dev, requires_grad=False)
+        return _ForwardDiffusionFn.apply(_lib.load(), _f32c(x0, dev), _f32c(mask, dev), _f32c(t, dev), _f32c(z, dev),
+                                         float(self.beta_min), float(self.beta_max))
 
     def loss_t(self, x0, mask, cond, t, spk_emb):
-        """`loss_t`, unitspeech/unitspeech.py:393-405."""
-        xt, z = self.forward_diffusion(x0, mask, t)
-        time = t.unsqueeze(-1).unsqueeze(-1)
-        cum_noise = get_noise(time, self.beta_min, self.beta_max, cumulative=True)
-        cond = cond * mask
-        noise_estimation = self.estimator(xt, mask, cond, t, spk_emb)
-        noise_estimation = noise_estimation * torch.sqrt(1.0 - torch.exp(-cum_noise))
-        loss = torch.sum((noise_estimation + z) ** 2) / (torch.sum(mask) * self.n_feats)
+        """`loss_t`, unitspeech/unitspeech.py:393-405: noising, conditioning mask, score network, objective -- four calls into
+        the library, differentiable w.r.t. the decoder parameters and w.r.t. x0 / cond / spk_emb."""
+        lib, dev = _lib.load(), x0.device
+        B, F, T = x0.shape
+        _check_shapes(B, F, T, self.spk_uncon.shape[-1], cond=cond, mask=mask, spk_emb=spk_emb, t=t)
+        mask_, t_ = _f32c(mask, dev), _f32c(t, dev)
+        xt, z_masked = self.forward_diffusion(x0, mask_, t_)
+        score = self.estimator(xt, mask_, _MulMaskFn.apply(lib, _f32c(cond, dev), mask_), t_, spk_emb)
+        loss = _DiffusionLossFn.apply(lib, score, z_masked, t_, mask_, float(self.beta_min), float(self.beta_max))
         return loss, xt
 
     def compute_loss(self, x0, mask, cond, spk_emb=None, offset=1e-5):
-        """`compute_loss`, unitspeech/unitspeech.py:407-411."""
-        t = torch.rand(x0.shape[0], dtype=x0.dtype, device=x0.device, requires_grad=False)
-        t = torch.clamp(t, offset, 1.0 - offset)
+        """`compute_loss`, unitspeech/unitspeech.py:407-411: t ~ U[offset, 1 - offset] per item (torch's generator, drawn before
+        the noise as in the reference)."""
+        t = torch.rand(x0.shape[0], dtype=x0.dtype, device=x0.device, requires_grad=False).clamp_(offset, 1.0 - offset)
         return self.loss_t(x0, mask, cond, t, spk_emb)
 
     def fine_tune(self, cond_x, y, y_mask, y_lengths, y_max_length, attn, spk_emb, segment_size, n_feats):
-        """`fine_tune`, unitspeech/unitspeech.py:452-493: crop one random `segment_size` window per item (offset from
-        Python's `random`, :461), align the unit-encoder output to it and evaluate the diffusion loss."""
-        if y_max_length < segment_size:
-            pad = segment_size - y_max_length
-            y = torch.nn.functional.pad(y, (0, pad))
-            y_mask = torch.nn.functional.pad(y_mask, (0, pad))
-        room = (y_lengths - segment_size).clamp(0).cpu().tolist()
-        starts = [random.choice(range(0, int(r))) if r > 0 else 0 for r in room]
-        B = y.shape[0]
-        attn_seg = attn.new_zeros(attn.shape[0], attn.shape[1], segment_size)
-        y_seg = y.new_zeros(B, n_feats, segment_size)
-        seg_lengths = []
-        for i, lo in enumerate(starts):
-            n = segment_size + int((y_lengths[i] - segment_size).clamp(None, 0))
-            seg_lengths.append(n)
-            y_seg[i, :, :n] = y[i, :, lo:lo + n]
-            attn_seg[i, :, :n] = attn[i, :, lo:lo + n]
-        seg_mask = sequence_mask(torch.LongTensor(seg_lengths)).unsqueeze(1).to(y_mask)
-        if seg_mask.shape[-1] < segment_size:
-            seg_mask = torch.nn.functional.pad(seg_mask, (0, segment_size - seg_mask.shape[-1]))
-        cond_y = torch.matmul(attn_seg.transpose(1, 2).contiguous(), cond_x.transpose(1, 2).contiguous())
-        cond_y = cond_y.transpose(1, 2).contiguous() * seg_mask
+        """`fine_tune`, unitspeech/unitspeech.py:452-493.  Per item one window of `segment_size` frames: the offset comes from
+        Python's `random.choice(range(0, y_length - segment_size))` exactly as in the reference (:458-462, same generator
+        consumption); `us_finetune_segment` then crops y, aligns the unit-encoder output to the window (attn_cut^T cond_x, masked)
+        and builds the window mask in one pass -- items shorter than the window are zero-extended, so no padded copies of y /
+        y_mask are made (:453-456)."""
+        dev = y.device
+        B, Ly = y.shape[0], y.shape[-1]
+        lens = [int(v) for v in y_lengths.cpu().tolist()]
+        starts = [random.choice(range(0, n - segment_size)) if n > segment_size else 0 for n in lens]
+        counts = [min(n, segment_size) for n in lens]
+        if attn.dim() == 4:
+            attn = attn.squeeze(1)
+        Lu = attn.shape[1]
+        if tuple(attn.shape) != (B, Lu, Ly) or tuple(cond_x.shape) != (B, n_feats, Lu) or y.shape[1] != n_feats:
+            raise ValueError(f"fine_tune: cond_x {tuple(cond_x.shape)}, y {tuple(y.shape)}, attn {tuple(attn.shape)} do not fit together")
+        meta = torch.tensor([starts, counts], dtype=torch.int64).to(dev)
+        y_seg = torch.empty(B, n_feats, segment_size, dtype=torch.float32, device=dev)
+        cond_y = torch.empty_like(y_seg)
+        seg_mask = torch.empty(B, 1, segment_size, dtype=torch.float32, device=dev)
+        cx, yy, at = _f32c(cond_x, dev), _f32c(y, dev), _f32c(attn, dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().us_finetune_segment(_dev_ptr(cx), _dev_ptr(yy), _dev_ptr(at), _dev_ptr(meta[0]), _dev_ptr(meta[1]),
+                                                 _dev_ptr(y_seg), _dev_ptr(cond_y), _dev_ptr(seg_mask), B, n_feats, Lu, Ly,
+                                                 int(segment_size), _stream())
+        _lib.check(rc, None, "us_finetune_segment")
         diff_loss, _ = self.compute_loss(y_seg, seg_mask, cond_y, spk_emb=spk_emb)
         return diff_loss
 
     @torch.no_grad()
     def execute_text_to_speech(self, phoneme, phoneme_lengths, spk_emb, text_encoder, duration_predictor,
                                num_downsamplings_in_unet, diffusion_steps=50, length_scale=1.0, text_gradient_scale=1.0,
-                               spk_gradient_scale=1.0):
-        """`execute_text_to_speech`, unitspeech/unitspeech.py:413-450 (encoder and duration predictor stay on the
-        caller's PyTorch modules; only the decoder call runs on the HIP path)."""
+                               spk_gradient_scale=1.0, *, mel_range=None, **sampler_kw):
+        """`execute_text_to_speech`, unitspeech/unitspeech.py:413-450.  The text encoder and the duration predictor are the
+        caller's modules (:421-422); everything between them and the sampler runs in the library: `us_tts_durations`
+        (ceil(exp(logw) * x_mask) * length_scale and the frame counts, :424-427), one host read of the longest utterance
+        (:428, as in the reference) and `us_tts_align` (`generate_path` + attn^T cond_x + `sequence_mask`, :431-438).
+        Returns (encoder_outputs, decoder_outputs, attn) cropped as the reference crops them (its `attn[:, :, :y_max_length]`
+        acts on the symbol axis of the 4-D path, :450).  mel_range=(mel_min, mel_max): decoder_outputs de-normalised for the
+        vocoder (inference.py:140)."""
+        lib = _lib.load()
         cond_x, x, x_mask = text_encoder(phoneme, phoneme_lengths)
         logw = duration_predictor(x, x_mask, w=None, g=spk_emb, reverse=True)
-        w_ceil = torch.ceil(torch.exp(logw) * x_mask) * length_scale
-        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
-        y_max_length = int(y_lengths.max())
-        y_max_length_ = fix_len_compatibility(y_max_length, num_downsamplings_in_unet)
-        y_mask = sequence_mask(y_lengths, y_max_length_).unsqueeze(1).to(x_mask.dtype)
-        attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
-        attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
-        cond_y = torch.matmul(attn.squeeze(1).transpose(1, 2).contiguous(), cond_x.transpose(1, 2).contiguous())
-        cond_y = cond_y.transpose(1, 2).contiguous()
-        encoder_outputs = cond_y[:, :, :y_max_length]
-        z = torch.randn_like(cond_y, device=cond_y.device)
-        decoder_outputs = self.forward(z, y_mask, cond_y, spk_emb, n_timesteps=diffusion_steps,
-                                       text_gradient_scale=text_gradient_scale, spk_gradient_scale=spk_gradient_scale)
-        return encoder_outputs, decoder_outputs[:, :, :y_max_length], attn[:, :, :y_max_length]
+        dev = cond_x.device
+        B, F, L = cond_x.shape
+        cx, lw, xm = _f32c(cond_x, dev), _f32c(logw, dev).reshape(B, L), _f32c(x_mask, dev).reshape(B, L)
+        w_ceil = torch.empty(B, L, dtype=torch.float32, device=dev)
+        y_lengths = torch.empty(B, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.us_tts_durations(_dev_ptr(lw), _dev_ptr(xm), _dev_ptr(w_ceil), _dev_ptr(y_lengths), B, L, float(length_scale), _stream())
+        _lib.check(rc, None, "us_tts_durations")
+        y_max_length = int(y_lengths.max())                                        # host sync, :428
+        Tp = fix_len_compatibility(y_max_length, num_downsamplings_in_unet)
+        cond_y = torch.empty(B, F, Tp, dtype=torch.float32, device=dev)
+        attn = torch.empty(B, 1, L, Tp, dtype=torch.float32, device=dev)
+        y_mask = torch.empty(B, 1, Tp, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.us_tts_align(_dev_ptr(cx), _dev_ptr(w_ceil), _dev_ptr(xm), _dev_ptr(y_lengths), _dev_ptr(cond_y), _dev_ptr(attn),
+                                  _dev_ptr(y_mask), B, F, L, Tp, _stream())
+        _lib.check(rc, None, "us_tts_align")
+        z = torch.randn_like(cond_y, device=dev)                                    # RNG draw #0 of the reference (:441)
+        dec = self.forward(z, y_mask, cond_y, spk_emb, n_timesteps=diffusion_steps, text_gradient_scale=text_gradient_scale,
+                           spk_gradient_scale=spk_gradient_scale, mel_range=mel_range, **sampler_kw)
+        return cond_y[:, :, :y_max_length], dec[:, :, :y_max_length], attn[:, :, :y_max_length]
