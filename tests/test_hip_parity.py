@@ -423,21 +423,28 @@ def test_long_utterance_properties(full):
     assert torch.equal(a[:1], one)
 
 
-def test_split_precision_winograd_gemm_switch(full):
-    """US_WINO_BF16X6=1 (experimental, off by default): the Winograd GEMMs of the two low-resolution levels as six bf16 MFMA
-    products of three-way split operands with fp32 accumulation.  Must stay at the fp32 path's error level against the oracle and
-    keep batch composition out of the result."""
+def test_f16x3_winograd_gemms_match_the_fp32_path(full):
+    """Default path: Winograd GEMMs as three fp16 MFMA products of two-plane split operands (fp32 accumulation) against the same
+    GEMMs on the exact-fp32 matrix instruction (US_F16X3=0) and the oracle: same error level, batch composition stays out of the
+    result, and the fused / separate output-transform forms still agree bit for bit."""
     _, sd = full
-    m = _model_with_env(FULL, US_WINO_BF16X6=1)
     T = 64
     inp = G(synthetic_inputs(FULL, 3, T, seed=41, lengths=[T, T - 5, 40]))
     t = torch.tensor([0.3, 0.6, 0.9])
     args = [inp[k].to(DEV) for k in ("z", "mask", "cond")] + [t.to(DEV), inp["spk_emb"].to(DEV)]
-    with torch.no_grad():
-        out = m.estimator(*args)
-        one = m.estimator(*(a[1:2] for a in args))
     ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["cond"], t, inp["spk_emb"])
-    e = l1(out, ref)
-    print(f"\nbf16x6 switch: estimator L1 vs oracle {e:.3e}")
-    assert e <= 2e-6
-    assert torch.equal(out[1:2], one)
+    outs = {}
+    for name, env in (("f16x3", {}), ("fp32", {"US_F16X3": 0}), ("f16x3_fused", {"US_WINO_FUSE_MIN_WGS": 1}),
+                      ("f16x3_separate", {"US_WINO_FUSE_MIN_WGS": 10 ** 9}), ("f16x3_tm64", {"US_F16_TM": 64})):
+        m = _model_with_env(FULL, **env)
+        with torch.no_grad():
+            outs[name] = m.estimator(*args)
+            if name == "f16x3":
+                one = m.estimator(*(a[1:2] for a in args))
+    e16, e32 = l1(outs["f16x3"], ref), l1(outs["fp32"], ref)
+    print(f"\nestimator L1 vs oracle: f16x3 {e16:.3e}, fp32 MFMA {e32:.3e}; f16x3 vs fp32 {l1(outs['f16x3'], outs['fp32']):.3e}")
+    assert e16 <= 2e-6 and e32 <= 2e-6
+    assert e16 <= 1.5 * e32 + 1e-7
+    assert torch.equal(outs["f16x3"][1:2], one)
+    assert torch.equal(outs["f16x3_fused"], outs["f16x3_separate"])
+    assert torch.equal(outs["f16x3_tm64"], outs["f16x3_separate"])

@@ -30,6 +30,38 @@ __global__ void mfma_peak_kernel(float* out, int iters, unsigned long long* clk)
   if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
+// in-place fp32 -> f16x3 operand format (two interleaved fp16 planes per group of 8 values), for timing the F16 instantiations
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__global__ void to_f16x2_kernel(float* x, size_t n8) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float v[8];
+    for (int k = 0; k < 8; ++k) v[k] = x[i * 8 + k];
+    _Float16* h = reinterpret_cast<_Float16*>(x + i * 8);
+    for (int k = 0; k < 8; ++k) { _Float16 hi = (_Float16)v[k]; h[k] = hi; h[8 + k] = (_Float16)((v[k] - (float)hi) * 2048.f); }
+  }
+}
+
+// pure v_mfma_f32_32x32x16_f16 stream on random-ish operands: the ceiling of the f16x3 GEMMs (x 1/3 in fp32-equivalent FLOPs)
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+__global__ void mfma_f16_peak_kernel(float* out, int iters, unsigned long long* clk) {
+  f32x16 a0, a1, a2, a3;
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }
+  half8v x, y;
+  for (int k = 0; k < 8; ++k) { x[k] = (_Float16)(0.37f * ((threadIdx.x * 7 + k * 13) % 29) - 5.f); y[k] = (_Float16)(0.11f * ((threadIdx.x * 3 + k * 5 + blockIdx.x) % 31) - 1.7f); }
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, y, a3, 0, 0, 0);
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
 // Structural calibration: the conv kernel's inner-loop skeleton (TM=64 variant: 2 accumulators, 32 MFMAs per step) with
 // its ingredients switched on one at a time.  FLAGS: 1 = barrier per step, 2 = 12 ds_read_b128 per step, 4 = 6 LDS-DMA
 // pieces per step (double-buffered like the real kernel).
@@ -106,6 +138,19 @@ static void calibrate() {
     run_skeleton<7, 6, 1>(g, out); run_skeleton<7, 4, 1>(g, out); run_skeleton<7, 3, 1>(g, out); run_skeleton<7, 2, 1>(g, out);
     CK(hipFree(g));
   }
+  for (int wps : {1, 2}) {
+    int blocks = 256 * wps, iters = 40000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_f16_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, clk);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(mfma_f16_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, clk);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+    double fl = (double)blocks * 4 * iters * 4 * 32768.0;
+    printf("calibration: pure MFMA f16 32x32x16 stream, %d wave(s)/SIMD: %.1f TFLOP/s (= %.1f fp32-equivalent as f16x3), shader clock %.3f GHz\n",
+           wps, fl / ms / 1e9, fl / ms / 1e9 / 3, (double)h[0] / (double)h[1] * 0.1);
+  }
   for (int wps : {1, 2, 4}) {
     int blocks = 256 * wps;   // 256-thread blocks: 4 waves = 1 per SIMD
     int iters = 20000;
@@ -140,6 +185,11 @@ int main(int argc, char** argv) {
                     {"W2 gemm 512->512", 48, 10, 128, 512, 512, 1, 1}, {"W3 gemm 1024->1024", 48, 5, 64, 1024, 1024, 1, 1},
                     {"W3 gemm 2048->512", 48, 5, 64, 2048, 512, 1, 1}, {"W3 gemm 512->512", 48, 5, 64, 512, 512, 1, 1},
                     {"W0 gemm 128->128", 48, 40, 512, 128, 128, 1, 1},
+                    // the same GEMMs with the 3 items of a frequency folded into M (what the decoder launches)
+                    {"G1 gemm 256->256", 16, 60, 256, 256, 256, 1, 1}, {"G1 gemm 512->128", 16, 60, 256, 512, 128, 1, 1},
+                    {"G2 gemm 512->512", 16, 30, 128, 512, 512, 1, 1}, {"G2 gemm 1024->256", 16, 30, 128, 1024, 256, 1, 1},
+                    {"G3 gemm 1024->1024", 16, 15, 64, 1024, 1024, 1, 1}, {"G3 gemm 2048->512", 16, 15, 64, 2048, 512, 1, 1},
+                    {"G3 gemm 512->512", 16, 15, 64, 512, 512, 1, 1}, {"G0 gemm 128->128", 16, 120, 512, 128, 128, 1, 1},
                     // wino = 2: output transform fused (B = items, H x W = tile grid, output 2H x 2W)
                     {"F0 fused 128->128", 3, 40, 512, 128, 128, 1, 2}, {"F1 fused 256->256", 3, 20, 256, 256, 256, 1, 2},
                     {"F1 fused 512->256", 3, 20, 256, 512, 256, 1, 2}, {"F2 fused 512->512 B24", 24, 10, 128, 512, 512, 1, 2},
@@ -154,12 +204,19 @@ int main(int argc, char** argv) {
     float *in, *out, *w, *bias;
     CK(hipMalloc(&in, n_in * 4)); CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&w, n_w * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
     CK(launch_fill_normal(in, n_in, 1, 1, 0)); CK(launch_fill_normal(w, n_w, 1, 2, 0)); CK(launch_fill_normal(bias, sh.Cout, 1, 3, 0));
-    for (int tm : {128, 64}) {
+    const bool f16 = getenv("CB_F16") != nullptr;
+    if (f16) {
+      if (sh.wino) hipLaunchKernelGGL(to_f16x2_kernel, dim3(4096), dim3(256), 0, 0, in, n_in / 8);
+      hipLaunchKernelGGL(to_f16x2_kernel, dim3(4096), dim3(256), 0, 0, w, n_w / 8);
+    }
+    for (int tm : {256, 128, 64}) {
+      if (tm == 256 && !(f16 && sh.wino != 2)) continue;
       ConvArgs a; memset(&a, 0, sizeof a);
       a.in = in; a.in_ld = sh.Cin; a.wt = w; a.bias = bias; a.out = out; a.out_ld = sh.Cout; a.zeros = zeros;
       a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;
       a.ostep = 1; a.istride = 1; a.ntaps = sh.taps; a.bk = 32; a.tm = tm; a.omask_bmod = 1; a.debug = debug;
       a.splitk_ws = skws; a.splitk_ws_floats = skfl;
+      a.f16 = f16 ? (sh.wino ? 1 : 2) : 0;
       if (sh.wino == 1) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wt_bdiv = sh.B / 16; a.splitk_ws = nullptr; }
       if (sh.wino == 2) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wino_out = 1; a.ostep = 2; a.Hout = 2 * sh.H; a.Wout = 2 * sh.W; a.splitk_ws = nullptr; }
       if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }
@@ -186,7 +243,7 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
       }
       double fl = 2.0 * sh.B * sh.H * sh.W * (double)sh.Cin * sh.Cout * sh.taps * (sh.wino == 2 ? 16 : 1);
-      printf("%-20s tm=%3d debug=%d  %8.1f us  %6.1f TFLOP/s\n", sh.name, tm, debug, ms * 1e3, fl / ms / 1e9);
+      printf("%-20s tm=%3d %s debug=%d  %8.1f us  %6.1f TFLOP/s\n", sh.name, tm, f16 ? "f16x3" : "fp32 ", debug, ms * 1e3, fl / ms / 1e9);
     }
     CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
   }

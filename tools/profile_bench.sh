@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 kernel trace of one bench.py sampling call -> per-kernel stats + per-launch conv table under gpurun_out/<tag>/
+# usage (on the GPU box, from the repo root): tools/profile_bench.sh <tag> [extra bench.py args]
+set -u
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/$tag
+rm -rf "$out"; mkdir -p "$out"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
+trace=$(find "$out" -name '*kernel_trace.csv' | head -1)
+stats=$(find "$out" -name '*kernel_stats.csv' | head -1)
+if [ -z "$trace" ] || [ -z "$stats" ]; then echo "no trace produced"; tail -5 "$out/bench.log"; exit 1; fi
+python3 tools/analyze_trace.py "$trace" > "$out/conv_per_launch.txt" || true
+cp "$stats" "$out/kernel_stats.csv"
+find "$out" -name '*kernel_trace.csv' -delete
+tail -3 "$out/conv_per_launch.txt"
+head -12 "$out/kernel_stats.csv" | cut -c1-140

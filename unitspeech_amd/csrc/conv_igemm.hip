@@ -30,6 +30,7 @@ namespace us {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int TN = 128;
 
@@ -49,14 +50,39 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // (coefficients 0/+-1, same order as wino_output_kernel, so both forms give the same bits); the epilogue then runs once per
 // output position (oy0, ox0) = (r, q) of the 2x2 tile with ostep = 2.  Saves the [16][B][tiles][Cout] round trip through
 // HBM and the output-transform pass, for 16x fewer (16x longer) workgroups: used where those still fill the chip.
-template <int BK, int WM, bool WINO>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int TM = 2 * WM;         // rows (pixels) per workgroup
+//
+// F16 = true ("f16x3"): the same GEMM at fp32 accuracy on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA
+// rate per instruction).  Both operands arrive as TWO fp16 planes per value, x ~= hi + lo * 2^-11 with hi = fp16(x) and
+// lo = fp16((x - hi) * 2^11) (22 significant bits; written by the Winograd input transforms / at weight load), stored
+// interleaved so that a row of 32 channels is still 128 bytes: [8 x hi][8 x lo] per group of 8 channels.  The DMA, the LDS image
+// and its swizzle are therefore byte-for-byte those of the fp32 kernel; only the fragment reads (one 16-byte chunk = 8
+// channels of one plane = one MFMA operand) and the MFMAs differ.  Three products per 16-deep step,
+//   C_hh += a_hi b_hi;   C_x += a_hi b_lo + a_lo b_hi;   C = C_hh + 2^-11 C_x        (a_lo b_lo ~ 2^-22 is dropped),
+// i.e. 16/3 = 5.3x the fp32 MFMA rate; fp16 products are exact in the fp32 accumulator, so the error is the fp32 accumulation's
+// (measured: mean error of a K = 1,152 GEMM 3.40e-7 of mean|C| against 3.38e-7 for an fp32 sgemm).  The scaled lo plane is a
+// normal fp16 whenever hi is, so no operand scaling is needed for |x| in [6e-5, 65504]; smaller values lose nothing that matters
+// (absolute error floor 1.5e-11), larger ones are clamped by the producers.
+//
+// NWM = waves along M (2: 256 threads, 4: 512 threads = two waves per SIMD); NSTG = LDS operand buffers.  NSTG = 3 is the f16x3
+// GEMMs' pipeline: their 32-channel step is 24 MFMAs of 32 cycles per wave instead of 32 of 64, too short to cover the latency
+// of a DMA issued one step ahead (measured with two buffers: 29 % of the fp16 MFMA rate, waves parked on vmcnt(0) at the
+// barrier), so chunk s+2 is issued at step s, a counted `s_waitcnt vmcnt(pieces of one chunk)` retires only chunk s, and the
+// barrier is a raw s_barrier (a __syncthreads() would drain the chunk still in flight).
+//
+// ASPLIT (with F16): the A operand is an ordinary fp32 activation tensor (every direct convolution: 3x3, 1x1, stride 2, transposed);
+// it goes through the DMA and the LDS image unchanged and each wave splits the 8 channels of a fragment into the two fp16 planes in
+// registers (v_cvt_pk_f16_f32, back-conversion, subtract, scale, v_cvt_pk_f16_f32: about 4 VALU operations per value, issued
+// beside the MFMAs).  Only the weights are pre-split.
+template <int BK, int WM, bool WINO, bool F16 = false, int NWM = 2, int NSTG = 2, bool ASPLIT = false>
+__global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int NW = 2 * NWM;        // waves per workgroup, NWM (M) x 2 (N)
+  constexpr int TM = NWM * WM;       // rows (pixels) per workgroup
   constexpr int MB = WM / 32;        // 32-row MFMA blocks per wave along M
   constexpr int CPR = BK / 4;        // 16-byte chunks per tile row
   constexpr int RPI = 64 / CPR;      // rows covered by one wave-wide DMA instruction
-  constexpr int IA = TM / RPI / 4;   // DMA instructions per wave for the A tile
-  constexpr int IB = TN / RPI / 4;   // ... for the B tile
+  constexpr int IA = TM / RPI / NW;  // DMA instructions per wave for the A tile
+  constexpr int IB = TN / RPI / NW;  // ... for the B tile
+  static_assert(NSTG == 2 || (NSTG == 3 && !WINO), "three operand buffers: plain GEMM form only");
   constexpr int SWZ_DIV = 64 / BK;   // rows per 256-byte bank window
   constexpr int BUF = (TM + TN) * BK;  // floats per LDS buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -196,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((long long)f * a.B + b) * a_item), 0, (int)a_bytes, 0x00020000);
     rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wt + (long long)f * a.wt_bstride), 0, 0x7fffffff, 0x00020000);
   };
-  // a frequency whose K = Cin fits one accumulation chain never touches `total`
-  const bool two_level = !WINO || nchunk > kFlushSteps;
+  // a frequency whose K = Cin fits one accumulation chain never touches `total`; F16: `acc` is C_hh and `total` is C_x
+  const bool two_level = !F16 && (!WINO || nchunk > kFlushSteps);
   auto fold = [&](int f) {
     // At = [1 1 1 0; 0 1 -1 -1]: coefficient of M_f (f = 4*fi + fj) in output (r, q) is At[r][fi] * At[q][fj]; 7 of the 16
     // frequencies feed one output, 6 feed two, 4 feed four: zero coefficients are skipped (wave-uniform branches)
@@ -205,6 +231,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const float r0 = fi < 3 ? 1.f : 0.f, r1 = fi == 0 ? 0.f : (fi == 1 ? 1.f : -1.f);
     const float q0 = fj < 3 ? 1.f : 0.f, q1 = fj == 0 ? 0.f : (fj == 1 ? 1.f : -1.f);
     const float cf[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
+    if (F16) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[i][j][r] = __builtin_fmaf(total[i][j][r], 0x1p-11f, acc[i][j][r]); total[i][j][r] = 0.f; }
+    }
     if (two_level) {
 #pragma unroll
       for (int i = 0; i < MB; ++i)
@@ -240,14 +274,58 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   setup_tap(WINO ? 0 : tap_n);
   dma(ch_n, 0);
   if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
-  __syncthreads();
+  if (NSTG == 3) {
+    if (S_run > 1) {
+      if (ch_n == 0) setup_tap(tap_n);
+      dma(ch_n, 1);
+      if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+    }
+  } else {
+    __syncthreads();
+  }
 
   // Fragment reads are double-buffered in registers (set 0 / set 1) and the MFMAs of a step's LAST sub-step are
   // deferred until after the barrier and after the next step's first fragment reads have been issued, so the LDS
   // latency behind the barrier is covered by 8*MB MFMAs instead of idling the matrix pipe.
-  constexpr int NS = BK / 8;
-  f32x4 fa0[MB], fb0[2], fa1[MB], fb1[2];
+  constexpr int NS = F16 ? 2 : BK / 8;    // F16: two 16-deep steps per 32-channel chunk
+  constexpr int NP = F16 ? 2 : 1;         // fp16 planes per operand
+  f32x4 fa0[MB * NP], fb0[2 * NP], fa1[MB * NP], fb1[2 * NP];
   auto load_frags = [&](f32x4* fa, f32x4* fb, const float* base, int s_) {
+    if (F16) {
+      // chunk (2 * kgroup + plane) of the row; lane half hh supplies channels 8 * (2 s + hh) .. + 7 of the chunk's 32
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int co = ((((2 * s_ + hh) << 1) + p) ^ sw) * 4;
+        if (!ASPLIT) {
+#pragma unroll
+          for (int i = 0; i < MB; ++i) fa[i * 2 + p] = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + co);
+        }
+        fb[p] = *reinterpret_cast<const f32x4*>(base + b_row + co);
+        fb[2 + p] = *reinterpret_cast<const f32x4*>(base + b_row + 32 * BK + co);
+      }
+      if (ASPLIT) {
+        // fp32 row: the same 8 channels are two 16-byte chunks of 4 floats; split them here
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + ((((2 * s_ + hh) << 1)) ^ sw) * 4);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + ((((2 * s_ + hh) << 1) + 1) ^ sw) * 4);
+          half8 hi, lo;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const _Float16 h0 = (_Float16)v0[k], h1 = (_Float16)v1[k];
+            hi[k] = h0; hi[4 + k] = h1;
+            lo[k] = (_Float16)((v0[k] - (float)h0) * 2048.f);
+            lo[4 + k] = (_Float16)((v1[k] - (float)h1) * 2048.f);
+          }
+          fa[i * 2] = __builtin_bit_cast(f32x4, hi);
+          fa[i * 2 + 1] = __builtin_bit_cast(f32x4, lo);
+        }
+      }
+#ifndef US_NO_SCHEDBAR
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      return;
+    }
     const int co = ((2 * s_ + hh) ^ sw) * 4;
 #pragma unroll
     for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + co);
@@ -260,6 +338,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #endif
   };
   auto mma = [&](const f32x4* fa, const f32x4* fb) {
+    if (F16) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const half8 ah = __builtin_bit_cast(half8, fa[i * 2]), al = __builtin_bit_cast(half8, fa[i * 2 + 1]);
+          const half8 bh = __builtin_bit_cast(half8, fb[j * 2]), bl = __builtin_bit_cast(half8, fb[j * 2 + 1]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+          total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, total[i][j], 0, 0, 0);
+          total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, total[i][j], 0, 0, 0);
+        }
+      return;
+    }
 #if US_PRIO_MODE == 2
     __builtin_amdgcn_s_setprio(1);
 #endif
@@ -288,6 +379,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
   };
 
+  if (NSTG == 3) {
+    // chunk s lives in buffer s % 3.  At step s: wait for this wave's pieces of chunk s (chunk s+1 may stay in flight), barrier
+    // (everybody's pieces have landed, and everybody is done reading chunk s-1, whose buffer chunk s+2 is about to overwrite),
+    // issue chunk s+2, multiply chunk s.
+    int cur = 0;
+    for (int step = 0; step < S_run; ++step) {
+      if (step + 1 < S_run) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + IB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (step + 2 < S_run) {
+        if (ch_n == 0) setup_tap(tap_n);
+        dma(ch_n, cur == 0 ? 2 : cur - 1);
+        if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+      }
+      const float* base = smem + cur * BUF;
+      load_frags(fa0, fb0, base, 0);
+      load_frags(fa1, fb1, base, 1);
+      mma(fa0, fb0);
+      if (NS == 4) {
+        load_frags(fa0, fb0, base, 2);
+        mma(fa1, fb1);
+        load_frags(fa1, fb1, base, 3);
+        mma(fa0, fb0);
+      }
+      mma(fa1, fb1);
+      step_done();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+  } else {
   for (int step = 0; step < S_run; ++step) {
     const bool has_next = step + 1 < S_run;
     if (has_next) {
@@ -349,11 +469,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   mma(fa1, fb1);
   if (WINO) fold(15);
 #endif
+  }   // NSTG == 2
   if (!WINO) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
+      for (int j = 0; j < 2; ++j) {
+        if (F16) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(total[i][j][r], 0x1p-11f, acc[i][j][r]);
+        } else {
+          acc[i][j] += total[i][j];
+        }
+      }
   }
 
   // ---- epilogue: C/D layout of the 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
@@ -556,12 +684,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
   }
 }
 
-static size_t lds_bytes(int bk, int tm) { return (size_t)2 * (tm + TN) * bk * sizeof(float); }
+static size_t lds_bytes(int bk, int tm, int nstg = 2) { return (size_t)nstg * (tm + TN) * bk * sizeof(float); }
 
-template <int BK, int WM, bool WINO>
+template <int BK, int WM, bool WINO, bool F16 = false, int NWM = 2, int NSTG = 2, bool ASPLIT = false>
 static hipError_t set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, WM, WINO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds_bytes(BK, 2 * WM));
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BK, WM, WINO, F16, NWM, NSTG, ASPLIT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(BK, NWM * WM, NSTG));
 }
 
 hipError_t conv_igemm_init() {
@@ -571,11 +699,19 @@ hipError_t conv_igemm_init() {
   if ((e = set_attr<16, 64, false>()) != hipSuccess) return e;
   if ((e = set_attr<16, 32, false>()) != hipSuccess) return e;
   if ((e = set_attr<32, 32, true>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 64, false, true>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 64, false, true, 4, 3>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 64, false, true, 4, 3, true>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 64, false, true, 2, 2, true>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 32, false, true, 2, 2, true>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 32, false, true>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 32, true, true>()) != hipSuccess) return e;
   return set_attr<16, 32, true>();
 }
 
 static int g_tm64_threshold = -1;
 static int g_splitk = -1;
+static int g_f16_tm = -1;      // US_F16_TM: rows per workgroup of the f16x3 GEMMs (128 or 64)
 
 hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
@@ -591,6 +727,10 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     int cg = a.Cout / kGroups;
     if (a.Cout % kGroups != 0 || (cg & (cg - 1)) != 0) return hipErrorInvalidValue;
   }
+  if (g_f16_tm < 0) {
+    const char* e = getenv("US_F16_TM");
+    g_f16_tm = e ? atoi(e) : 0;
+  }
   if (g_tm64_threshold < 0) {
     const char* e = getenv("US_TM64_THRESHOLD");
     // measured on MI355X (tools/conv_bench, bench.py): three co-resident 64-row workgroups per CU (136 VGPRs, 48 KB LDS)
@@ -600,6 +740,25 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const int Ms = a.Hs * a.Ws;
   const int nt = (a.Cout + TN - 1) / TN;
   int tm = a.tm;
+  if (a.f16) {
+    // f16x3: the weights are pre-split; f16 = 1: so is the A operand (Winograd-domain GEMMs, planes written by the input
+    // transforms); f16 = 2: A is a plain fp32 activation tensor, split in the kernel (any tap geometry)
+    if (a.bk != 32 || (a.f16 == 1 && (a.ntaps != 1 || a.istride != 1))) return hipErrorInvalidValue;
+    if (a.f16 == 1) a.splitk_ws = nullptr;
+    if (tm == 0 && g_f16_tm > 0) tm = g_f16_tm;
+    if (tm == 0) {
+      if (a.f16 == 1) {
+        // Winograd-domain GEMMs (all items of a frequency in one M range): the largest tile that still fills the chip
+        const long long per256 = (long long)((a.Hs * a.Ws + 255) / 256) * nt * a.B;
+        tm = per256 >= 384 ? 256 : 128;
+      } else {
+        // direct convolutions (A split in the kernel): three co-resident 64-row workgroups per CU beat the larger tiles at every
+        // U-Net shape (tools/conv_bench: 272 vs 251 vs 210 TFLOP/s on the level-0 3x3).  Never a function of the batch, so that
+        // the split-K slicing below, hence the summation order, does not depend on what an utterance is batched with.
+        tm = 64;
+      }
+    }
+  }
   if (a.wino_out) {
     // fused Winograd output transform: ntaps = 1, ostep = 2, Hs x Ws = tile grid, Hout x Wout = image, no split-K
     if (a.ntaps != 1 || a.ostep != 2 || a.istride != 1 || a.alpha) return hipErrorInvalidValue;
@@ -637,7 +796,16 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   }
   dim3 grid(mt * a.ksplit, nt, a.B * (a.nphase > 1 ? a.nphase : 1));
   const size_t lds = lds_bytes(a.bk, tm);
-  if (a.wino_out) {
+  if (a.f16 == 2) {
+    if (tm == 256) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 4, 3, true>), grid, dim3(512), lds_bytes(32, 256, 3), s, a);
+    else if (tm == 128) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 2, 2, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<32, 32, false, true, 2, 2, true>), grid, dim3(256), lds, s, a);
+  } else if (a.f16) {
+    if (a.wino_out) hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true, true>), grid, dim3(256), lds, s, a);
+    else if (tm == 256) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 4, 3>), grid, dim3(512), lds_bytes(32, 256, 3), s, a);
+    else if (tm == 128) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<32, 32, false, true>), grid, dim3(256), lds, s, a);
+  } else if (a.wino_out) {
     if (a.bk == 32)
       hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true>), grid, dim3(256), lds, s, a);
     else
@@ -677,6 +845,39 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __
                         : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
     dst[i] = src[si];
   }
+}
+
+// f16x3 form (bk = 32): dst (halves) [tap][Cin/32][Cout][4 groups x (8 hi | 8 lo)], same bytes and row structure as the fp32 pack
+__global__ void pack_conv_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin, int KH, int KW,
+                                            int oihw) {
+  const long long total = (long long)KH * KW * Cout * Cin;
+  const int nchunk = Cin / 32;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int k = (int)(i % 32);
+    long long t = i / 32;
+    int co = (int)(t % Cout); t /= Cout;
+    int ch = (int)(t % nchunk);
+    int tap = (int)(t / nchunk);
+    int ci = ch * 32 + k;
+    int ky = tap / KW, kx = tap % KW;
+    long long si = oihw ? (((long long)co * Cin + ci) * KH + ky) * KW + kx
+                        : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
+    const float c = fminf(fmaxf(src[si], -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;
+    const long long o = (i - k) * 2 + (k / 8) * 16 + k % 8;
+    dst[o] = h;
+    dst[o + 8] = (_Float16)fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+  }
+}
+
+hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s) {
+  if (Cin % 32 != 0) return hipErrorInvalidValue;
+  long long total = (long long)KH * KW * Cout * Cin;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_conv_weight_f16_kernel, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), Cout, Cin, KH, KW,
+                     oihw ? 1 : 0);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_conv_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk,

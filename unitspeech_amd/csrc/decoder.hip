@@ -38,7 +38,9 @@ struct Slot {
   DevBuf dg;             // conv kinds (and to_out): repack for the data-gradient GEMM [tap][Cout/bk_dg][Cin][bk_dg]
   int bk_dg = 0;
   DevBuf wino;           // 3x3 stride-1 convs of the Winograd levels: U = G g G^T, [16][Cin/bk][Cout][bk]
-  DevBuf wino_bf;        // experimental: U as three bf16 planes [3][16][Cout][Cin] (n counts floats of storage)
+  bool direct_f16 = false;  // buf (direct-form pack of a conv that does not run in the Winograd domain) holds the f16x3 form
+  bool wino_f16 = false;    // wino holds the f16x3 form (two interleaved fp16 planes per value) instead of fp32
+  bool wino_dg_f16 = false; // ... and so does wino_dg
   int level = -1;        // U-Net level of a ResnetBlock conv
   DevBuf wino_dg;        // ... and of the rotated, channel-swapped filter for the data gradient, [16][Cout/bk_dg][Cin][bk_dg]
   bool want_wino = false;
@@ -97,8 +99,9 @@ struct us_decoder {
   Slot *final_g, *final_b, *final_w1, *final_b1;
   Slot *text_uncon, *spk_uncon, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
   int n_resnets = 0;
-  bool bf16x6 = false;       // US_WINO_BF16X6=1 (experimental): the Winograd GEMMs of levels >= bf16x6_min_level as six bf16 MFMA
-  int bf16x6_min_level = 2;  // products of split operands (wino_gemm.hip); always the separate-transform form there
+  bool f16x3 = true;         // US_F16X3=0: every Winograd GEMM on the fp32 matrix instruction.  Default: those with 32-divisible
+  int f16x3_min_level = 0;   // channel counts at levels >= US_F16X3_MIN_LEVEL run as three fp16 MFMA products of split operands
+  bool f16x3_direct = true;  // US_F16X3_DIRECT=0: direct convolutions (1x1, stride 2, transposed, non-Winograd 3x3) stay on fp32 MFMA
   long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
   int wino_min_level = 0;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
@@ -252,6 +255,7 @@ struct us_decoder {
     mid2 = add_resnet("estimator.mid_block2", C[L - 1], C[L - 1], L - 1);
     final_conv3 = add_conv("estimator.final_block.block.0", cfg.dim, cfg.dim, 3, true);
     if (wino_min_level <= 0) final_conv3.w->want_wino = true;
+    final_conv3.w->level = 0;
     final_g = add("estimator.final_block.block.1.weight", {cfg.dim});
     final_b = add("estimator.final_block.block.1.bias", {cfg.dim});
     final_w1 = add("estimator.final_conv.weight", {1, cfg.dim, 1, 1});
@@ -364,7 +368,6 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false
   need_r(h->mid1); need_r(h->mid2);
   for (auto& u : h->ups) { need_r(u.r1); need_r(u.r2); }
   need(h->final_conv3, 0);
-  if (h->bf16x6) wv += wv / 2;          // three bf16 planes = 6 bytes per V element
   if (wv) { b.wino_v = A.alloc<float>(wv); b.wino_m = A.alloc<float>(wm); }
 }
 
@@ -404,6 +407,7 @@ ConvArgs base_args(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int H
   a.B = e.Bp; a.Hin = Hin; a.Win = Win; a.Cin = w.cin; a.Hout = Hout; a.Wout = Wout; a.Cout = w.cout;
   a.Hs = Hout; a.Ws = Wout; a.ostep = 1; a.istride = 1;
   a.bk = w.w->bk;
+  a.f16 = w.w->direct_f16 ? 2 : 0;      // f16x3 with the fp32 activations split inside the kernel
   a.omask_bmod = 1;
   a.zeros = e.h->zeros;
   a.splitk_ws = e.b->splitk;
@@ -437,40 +441,18 @@ struct WinoEpi {
   bool mask_out = false;
 };
 hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int K, int N, int bk, int level, float* out, int out_ld,
-                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr, const void* Ubf = nullptr) {
+                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr, bool f16 = false) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   Buffers& b = *e.b;
-  if (Ubf) {
-    // experimental split-precision form: V as three bf16 planes, six-product GEMM on the bf16 matrix cores, separate output transform
-    hipError_t e0 = gn ? (in_ld == K ? launch_gn_wino_input(in, b.wino_v, e.Bp, H, W, K, *gn, e.s, true) : hipErrorInvalidValue)
-                       : launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, e.s, true);
-    if (e0 != hipSuccess) return e0;
-    const int rows = e.Bp * th * tw;
-    us_decoder* h = e.h;
-    if (!h->prof_active) {
-      e0 = launch_wino_gemm_bf16x6(b.wino_v, Ubf, b.wino_m, rows, N, K, e.s);
-    } else {
-      us_decoder::ProfRec r;
-      r.a = h->prof_event(); r.b = h->prof_event(); r.kind = 0;
-      r.flops = 2.0 * 16 * (double)rows * N * (double)K;
-      (void)hipEventRecord(r.a, e.s);
-      e0 = launch_wino_gemm_bf16x6(b.wino_v, Ubf, b.wino_m, rows, N, K, e.s);
-      (void)hipEventRecord(r.b, e.s);
-      h->prof_pending.push_back(r);
-    }
-    if (e0 != hipSuccess) return e0;
-    WinoOutExtra x{};
-    x.add = ep.add; x.add_ld = ep.add_ld;
-    if (ep.mask_out) { x.mask = e.mask; x.mask_ld = e.T; x.mask_step = 1 << level; x.mask_bmod = e.Bm; }
-    return launch_wino_output(b.wino_m, ep.bias, out, out_ld, ep.stats, e.Bp, H, W, N, e.s, &x);
-  }
   // gn: `in` is block1's raw conv output (ld == K); its GroupNorm + Mish + time embedding are evaluated inside the transform
-  hipError_t err = gn ? (in_ld == K ? launch_gn_wino_input(in, b.wino_v, e.Bp, H, W, K, *gn, e.s) : hipErrorInvalidValue)
-                      : launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, e.s);
+  // f16: U is in the f16x3 form and V is written the same way (two interleaved fp16 planes per value, same bytes and strides)
+  hipError_t err = gn ? (in_ld == K ? launch_gn_wino_input(in, b.wino_v, e.Bp, H, W, K, *gn, e.s, f16) : hipErrorInvalidValue)
+                      : launch_wino_input(in, in_ld, b.wino_v, e.Bp, H, W, K, e.s, f16);
   if (err != hipSuccess) return err;
   ConvArgs a;
   memset(&a, 0, sizeof a);
+  a.f16 = f16 ? 1 : 0;
   a.in = b.wino_v; a.in_ld = K;
   a.wt = U; a.wt_bstride = (long long)N * K;
   a.Hin = th; a.Win = tw; a.Cin = K; a.Cout = N;
@@ -503,9 +485,10 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
     h->prof_pending.push_back(r);
     return err;
   }
-  a.wt_bdiv = e.Bp;
+  // separate form: the items of one frequency are contiguous in V and in M, and a 1x1 tap never leaves its row, so a frequency's
+  // GEMM runs over all Bp * th * tw rows at once (no partial tile per item: a level-3 item has only 320 rows)
   a.out = b.wino_m; a.out_ld = N;
-  a.B = 16 * e.Bp; a.Hout = th; a.Wout = tw; a.ostep = 1;
+  a.B = 16; a.Hin = a.Hs = a.Hout = e.Bp * th; a.Wout = tw; a.ostep = 1;
   err = run_conv(e, a);
   if (err != hipSuccess) return err;
   WinoOutExtra x{};
@@ -519,7 +502,7 @@ hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, 
   WinoEpi ep;
   ep.bias = w.b ? w.b->buf.p : nullptr;
   ep.stats = stats;
-  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn, w.w->wino_bf.p);
+  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn, w.w->wino_f16);
 }
 
 hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
@@ -642,11 +625,12 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
   CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, b.colM, b.colS, b.ctx_split, e.s));
   const int bk = pick_bk(kHidden);
-  CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s));
+  const bool f16 = e.h->f16x3 && e.h->f16x3_direct;
+  CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s, f16));
   ConvW eff;
   eff.cin = kHidden; eff.cout = at.dim;
-  Slot tmp;             // only .bk / .buf are read by base_args
-  tmp.bk = bk; tmp.buf.p = b.weff;
+  Slot tmp;             // only .bk / .buf / .direct_f16 are read by base_args
+  tmp.bk = bk; tmp.buf.p = b.weff; tmp.direct_f16 = f16;
   eff.w = &tmp; eff.b = nullptr;
   // every consumer of an attention output masks it (Downsample / Upsample input, skip concat, mid blocks)
   return conv1x1(e, eff, qkv, 3 * kHidden, l, true, out, out_ld, in, in_ld, at.g->buf.p, b.weff, (long long)at.dim * kHidden,
@@ -864,8 +848,9 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS")) h->wino_fuse_min_wgs = atoll(wf);
-  if (const char* wf = getenv("US_WINO_BF16X6")) h->bf16x6 = atoi(wf) != 0;
-  if (const char* wf = getenv("US_WINO_BF16X6_MIN_LEVEL")) h->bf16x6_min_level = atoi(wf);
+  if (const char* wf = getenv("US_F16X3")) h->f16x3 = atoi(wf) != 0;
+  if (const char* wf = getenv("US_F16X3_MIN_LEVEL")) h->f16x3_min_level = atoi(wf);
+  if (const char* wf = getenv("US_F16X3_DIRECT")) h->f16x3_direct = atoi(wf) != 0;
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
   h->build();
   {
@@ -893,13 +878,18 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
       ok = hipMalloc(reinterpret_cast<void**>(&s->wino.p), s->wino.n * sizeof(float)) == hipSuccess &&
            hipMalloc(reinterpret_cast<void**>(&s->wino_dg.p), s->wino_dg.n * sizeof(float)) == hipSuccess;
     }
-    if (ok && s->want_wino && h->bf16x6 && s->level >= h->bf16x6_min_level && wino_gemm_bf16x6_supported((int)s->shape[0], (int)s->shape[1])) {
-      s->wino_bf.n = (size_t)24 * s->shape[0] * s->shape[1];          // 3 planes x 16 frequencies of bf16 = 96 bytes per (co, ci)
-      ok = hipMalloc(reinterpret_cast<void**>(&s->wino_bf.p), s->wino_bf.n * sizeof(float)) == hipSuccess;
+    if (ok && !s->want_wino && s->kind != Kind::RAW && h->f16x3 && h->f16x3_direct) {
+      const long long cin = s->kind == Kind::CONV_OIHW ? s->shape[1] : s->shape[0];
+      s->direct_f16 = cin % 32 == 0;
+    }
+    if (ok && s->want_wino && h->f16x3 && s->level >= h->f16x3_min_level) {
+      // the forward GEMM sums over Cin, the data-gradient GEMM over Cout: each needs its K in whole 32-channel chunks
+      s->wino_f16 = s->shape[1] % 32 == 0;
+      s->wino_dg_f16 = s->shape[0] % 32 == 0;
     }
     if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); if (t->wino_bf.p) (void)hipFree(t->wino_bf.p); }
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); }
       return US_EHIP;
     }
   }
@@ -909,7 +899,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); if (s->wino_bf.p) (void)hipFree(s->wino_bf.p); }
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
@@ -947,14 +937,17 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
     case Kind::CONV_OIHW:
       // a conv that runs in the Winograd domain never reads its direct-form pack (conv3x3 takes the Winograd branch whenever
       // wino.p is set; every workspace plan of this handle then has the V/M scratch)
-      if (s->wino_bf.p) US_HIP(h, launch_wino_pack_weight_bf16(data, s->wino_bf.p, (int)s->shape[0], (int)s->shape[1], st));
-      if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
+      if (s->wino.p && s->wino_f16) US_HIP(h, launch_wino_pack_weight_f16(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], st));
+      else if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
+      else if (s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, st));
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
-      if (s->wino_dg.p) US_HIP(h, launch_wino_pack_weight(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], s->bk_dg, st, true));
+      if (s->wino_dg.p && s->wino_dg_f16) US_HIP(h, launch_wino_pack_weight_f16(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], st, true));
+      else if (s->wino_dg.p) US_HIP(h, launch_wino_pack_weight(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], s->bk_dg, st, true));
       else US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
       break;
     case Kind::CONVT_IOHW:
-      US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));
+      if (s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, st));
+      else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));
       US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk_dg, st));
       break;
   }

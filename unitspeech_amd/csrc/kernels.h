@@ -56,6 +56,8 @@ struct ConvArgs {
   int bk;                // 16 or 32: channel chunk the weights were packed for
   int tm;                // rows per workgroup: 128, 64 or 0 = choose from the grid size
   int ksplit;            // set by the launcher: K slices per tile (1 = single pass)
+  int f16;               // f16x3 GEMM (bk = 32): `wt` holds two interleaved fp16 planes per value; 1: so does `in` (Winograd domain),
+                         // 2: `in` is a plain fp32 tensor that the kernel splits on the fly (direct convolutions)
   int wino_out;          // 1: `in` = V [16][B][Hs][Ws][Cin], `wt` = 16 matrices wt_bstride apart; Winograd output transform in the kernel
   int splitk_by_batch;   // 1: the split-K slice count may depend on the batch (training); 0: per-item geometry only, so that an
                          // utterance's result never depends on what it is batched with (sampling)
@@ -88,6 +90,8 @@ hipError_t conv_igemm_init();   // one-time function attributes (dynamic LDS siz
 //   oihw = false: src is ConvTranspose2d [Cin][Cout][KH][KW]
 hipError_t launch_pack_conv_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk,
                                    hipStream_t s);
+// the same pack as two interleaved fp16 planes per value (f16x3 GEMM, bk = 32; same size)
+hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s);
 
 // ---- first layer (2 input channels) ---------------------------------------------------------------
 // in2: [Bp][F][T][2] = (mu, x) already masked; writes conv3x3 (pad 1) -> y[Bp][F*T][C] and the ResnetBlock's
@@ -132,7 +136,9 @@ hipError_t launch_attn_ctx_partial(const float* qkv, int B, int n, float* part_c
 constexpr int kAttnMaxSplit = 16;
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
                                     float* ctx, float* colM, float* colS, float* split_ws, hipStream_t s);
-hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s);
+// f16 = true (bk = 32): weff as two interleaved fp16 planes per value, for the f16x3 form of the folded to_out convolution
+hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s,
+                            bool f16 = false);
 inline int attn_nchunks(int n) { return (n + 127) / 128; }
 
 // ---- small dense layers ----------------------------------------------------------------------------
@@ -242,7 +248,8 @@ namespace us {
 // dgrad = true: the transform of the 180-degree-rotated, channel-swapped filter (data gradient), dst[16][Cout/bk][Cin][bk]
 hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s, bool dgrad = false);
 // x: [B][H][W][x_ld] (C channels) -> V: [16][B][th][tw][C], th = ceil(H/2), tw = ceil(W/2); zero padding outside the image
-// split = true: V is written as three bf16 planes [3][16][B][th][tw][C] (v = v1 + v2 + v3) for the bf16x6 GEMM (wino_gemm.hip)
+// split = true: V is written as two interleaved fp16 planes per value (same bytes; C % 8 == 0) for the f16x3 GEMM
+// (conv_igemm_kernel<.., F16 = true>)
 hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s, bool split = false);
 // V of d = (mish(GroupNorm(y)) * mask + temb) * mask, y a raw conv output [B][H][W][C] (ld = C): block1's gn_apply of a
 // ResnetBlock folded into the input transform of its second convolution (C a multiple of 32)
@@ -261,9 +268,6 @@ struct WinoOutExtra {
 };
 hipError_t launch_wino_output(const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
                               hipStream_t s, const WinoOutExtra* extra = nullptr);
-// ---- experimental bf16x6 Winograd GEMM (wino_gemm.hip) ---------------------------------------------------------------------
-bool wino_gemm_bf16x6_supported(int N, int K);
-// V: [3][16][rows][K] bf16 planes, U: [3][16][N][K] bf16 planes, M: [16][rows][N] fp32
-hipError_t launch_wino_gemm_bf16x6(const void* V, const void* U, float* M, int rows, int N, int K, hipStream_t s);
-hipError_t launch_wino_pack_weight_bf16(const float* src, void* dst, int Cout, int Cin, hipStream_t s);
+// f16x3 form of launch_wino_pack_weight (bk = 32): dst holds two interleaved fp16 planes per value, same size and row structure
+hipError_t launch_wino_pack_weight_f16(const float* src, float* dst, int Cout, int Cin, hipStream_t s, bool dgrad = false);
 }  // namespace us

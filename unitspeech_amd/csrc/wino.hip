@@ -10,27 +10,33 @@ namespace us {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ---- split-precision storage of V (experimental bf16x6 GEMM path, wino_gemm.hip) -------------------------------------------
-// SPLIT = true: V is kept as three bf16 planes v = v1 + v2 + v3 (8 significant bits each), plane stride `psplit` elements; the
-// GEMM then forms the six products of order >= 2^-16 on the bf16 matrix cores with fp32 accumulation (fp32-level error).
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// ---- f16x3 storage of V (conv_igemm_kernel<.., F16 = true>) -----------------------------------------------------------------
+// SPLIT = true: every value is kept as two fp16 planes, v ~= hi + lo * 2^-11 with hi = fp16(v), lo = fp16((v - hi) * 2^11), interleaved
+// per group of 8 channels as [8 x hi][8 x lo] so that a pixel row keeps its fp32 byte length (C * 4).  `idx` is the fp32 element
+// index of a channel quad (c % 4 == 0): its hi quad sits at half index 2 * (idx - idx % 8) + idx % 8, its lo quad 8 halves further.
+// |v| is clamped to the fp16 range (65504); the GEMM's fp32 accumulation then carries the same error as an fp32 GEMM.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_f16(const f32x4& v, half4& hi, half4& lo) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;
+    const float r = fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+    hi[k] = h;
+    lo[k] = (_Float16)r;
+  }
+}
 template <bool SPLIT>
-__device__ __forceinline__ void store_v(float* __restrict__ V, long long idx, long long psplit, const f32x4& v) {
+__device__ __forceinline__ void store_v(float* __restrict__ V, long long idx, const f32x4& v) {
   if (!SPLIT) {
     *reinterpret_cast<f32x4*>(V + idx) = v;
   } else {
-    __bf16* vb = reinterpret_cast<__bf16*>(V);
-    bf16x4 p1, p2, p3;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const __bf16 a1 = (__bf16)v[k];
-      const float r1 = v[k] - (float)a1;
-      const __bf16 a2 = (__bf16)r1;
-      p1[k] = a1; p2[k] = a2; p3[k] = (__bf16)(r1 - (float)a2);
-    }
-    *reinterpret_cast<bf16x4*>(vb + idx) = p1;
-    *reinterpret_cast<bf16x4*>(vb + psplit + idx) = p2;
-    *reinterpret_cast<bf16x4*>(vb + 2 * psplit + idx) = p3;
+    _Float16* vh = reinterpret_cast<_Float16*>(V);
+    half4 hi, lo;
+    split_f16(v, hi, lo);
+    const long long o = 2 * (idx & ~7LL) + (idx & 7);
+    *reinterpret_cast<half4*>(vh + o) = hi;
+    *reinterpret_cast<half4*>(vh + o + 8) = lo;
   }
 }
 
@@ -74,10 +80,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     for (int r = 0; r < 4; ++r) {
       // columns: v = t B
       f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1], v3 = tt[r][1] - tt[r][3];
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, 16 * plane, v0);
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, 16 * plane, v1);
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, 16 * plane, v2);
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, 16 * plane, v3);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, v0);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, v1);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, v2);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, v3);
     }
   }
 }
@@ -173,10 +179,10 @@ __global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1], v3 = tt[r][1] - tt[r][3];
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, 16 * plane, v0);
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, 16 * plane, v1);
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, 16 * plane, v2);
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, 16 * plane, v3);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, v0);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, v1);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, v2);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, v3);
   }
 }
 
@@ -330,6 +336,51 @@ __global__ void wino_pack_weight_kernel(const float* __restrict__ src, float* __
       dst[base + (r * 4 + 3) * fstride] = u3;
     }
   }
+}
+
+// f16x3 form of the same pack (bk = 32): U as two interleaved fp16 planes, dst (halves) [f][K/32][N][4 groups x (8 hi | 8 lo)],
+// K = Cin, N = Cout (forward) or K = Cout, N = Cin (dgrad)
+__global__ void wino_pack_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin, int dgrad) {
+  const long long total = (long long)Cout * Cin;
+  const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+  const long long fstride = (long long)K * N * 2;        // halves per frequency
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), co = (int)(i / Cin);
+    const float* gs = src + i * 9;
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = dgrad ? gs[8 - k] : gs[k];
+    float gg[4][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      gg[0][q] = g[q];
+      gg[1][q] = 0.5f * (g[q] + g[3 + q] + g[6 + q]);
+      gg[2][q] = 0.5f * (g[q] - g[3 + q] + g[6 + q]);
+      gg[3][q] = g[6 + q];
+    }
+    const int k = dgrad ? co : ci, n = dgrad ? ci : co;
+    const long long base = (((long long)(k / 32) * N + n) * 32 + (k % 32 / 8) * 8) * 2 + k % 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float u[4] = {gg[r][0], 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]), 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]), gg[r][2]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float c = fminf(fmaxf(u[q], -65504.f), 65504.f);
+        const _Float16 h = (_Float16)c;
+        dst[base + (r * 4 + q) * fstride] = h;
+        dst[base + (r * 4 + q) * fstride + 8] = (_Float16)fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+      }
+    }
+  }
+}
+
+hipError_t launch_wino_pack_weight_f16(const float* src, float* dst, int Cout, int Cin, hipStream_t s, bool dgrad) {
+  if ((dgrad ? Cout : Cin) % 32 != 0) return hipErrorInvalidValue;
+  long long total = (long long)Cout * Cin;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wino_pack_weight_f16_kernel, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), Cout, Cin, dgrad ? 1 : 0);
+  return hipGetLastError();
 }
 
 hipError_t launch_wino_pack_weight(const float* src, float* dst, int Cout, int Cin, int bk, hipStream_t s, bool dgrad) {
