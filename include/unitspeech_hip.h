@@ -176,6 +176,10 @@ int us_debug_block(us_handle h, int kind, const char* prefix, int level, const f
 int us_profile_enable(us_handle h, int enable);
 int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* conv_launches, double* eval_ms,
                     int64_t* evals, int reset);
+/* The share of those conv launches that ran as f16x3 GEMMs (three fp16 MFMA products of two-plane split operands at fp32
+ * accuracy): their time, their fp32-equivalent FLOPs (2*M*N*K; the fp16 matrix cores execute three times that) and their
+ * count, as accumulated by the last us_profile_read (call it first, with reset = 0). */
+int us_profile_read_f16(us_handle h, double* f16_ms, double* f16_flops, int64_t* f16_launches);
 
 /* Gradient clipping + Adam over all parameter tensors in three launches.  Replaces torch.nn.utils.clip_grad_norm_(params, max_norm)
  * followed by torch.optim.Adam(lr, betas, eps, weight_decay=0).step()  (reference finetune.py:163-165, train_STEP1.py).

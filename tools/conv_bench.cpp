@@ -170,7 +170,8 @@ static void calibrate() {
 struct Shape { const char* name; int B, H, W, Cin, Cout, taps; int wino = 0; };   // wino: B = 16 frequencies x 3 items, one weight matrix per frequency
 
 int main(int argc, char** argv) {
-  int debug = argc > 1 ? atoi(argv[1]) : 0;
+  int debug_arg = argc > 1 ? atoi(argv[1]) : 0;
+  const int debug = debug_arg;
   CK(conv_igemm_init());
   if (debug == 0) calibrate();
   Shape shapes[] = {{"L0 3x3 128->128", 3, 80, 1024, 128, 128, 9}, {"L1 3x3 256->256", 3, 40, 512, 256, 256, 9},
@@ -209,14 +210,22 @@ int main(int argc, char** argv) {
       if (sh.wino) hipLaunchKernelGGL(to_f16x2_kernel, dim3(4096), dim3(256), 0, 0, in, n_in / 8);
       hipLaunchKernelGGL(to_f16x2_kernel, dim3(4096), dim3(256), 0, 0, w, n_w / 8);
     }
+    const int n_ab = getenv("CB_AB") ? 2 : 1;           // CB_AB=<bit>: every case also with that debug bit set, back to back
+    const int ab_bit = getenv("CB_AB") ? atoi(getenv("CB_AB")) : 0;
+    for (int ab = 0; ab < n_ab; ++ab)
     for (int tm : {256, 128, 64}) {
+      if (getenv("CB_TM") && atoi(getenv("CB_TM")) != tm) continue;
       if (tm == 256 && !(f16 && sh.wino != 2)) continue;
+      const int debug = debug_arg | (ab ? ab_bit : 0);
       ConvArgs a; memset(&a, 0, sizeof a);
       a.in = in; a.in_ld = sh.Cin; a.wt = w; a.bias = bias; a.out = out; a.out_ld = sh.Cout; a.zeros = zeros;
       a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;
       a.ostep = 1; a.istride = 1; a.ntaps = sh.taps; a.bk = 32; a.tm = tm; a.omask_bmod = 1; a.debug = debug;
       a.splitk_ws = skws; a.splitk_ws_floats = skfl;
       a.f16 = f16 ? (sh.wino ? 1 : 2) : 0;
+      static double* stats = nullptr;
+      if (!stats) { CK(hipMalloc(&stats, 1 << 20)); CK(hipMemset(stats, 0, 1 << 20)); }
+      if (getenv("CB_STATS") && sh.wino != 1) a.stats = stats;
       if (sh.wino == 1) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wt_bdiv = sh.B / 16; a.splitk_ws = nullptr; }
       if (sh.wino == 2) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wino_out = 1; a.ostep = 2; a.Hout = 2 * sh.H; a.Wout = 2 * sh.W; a.splitk_ws = nullptr; }
       if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }

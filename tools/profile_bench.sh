@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel trace of one bench.py sampling call -> per-kernel stats + per-launch conv table under gpurun_out/<tag>/
-# usage (on the GPU box, from the repo root): tools/profile_bench.sh <tag> [extra bench.py args]
+# usage (on the GPU box, from the repo root): tools/profile_bench.sh <tag> [extra bench.py args]; environment switches pass through
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -13,5 +13,12 @@ if [ -z "$trace" ] || [ -z "$stats" ]; then echo "no trace produced"; tail -5 "$
 python3 tools/analyze_trace.py "$trace" > "$out/conv_per_launch.txt" || true
 cp "$stats" "$out/kernel_stats.csv"
 find "$out" -name '*kernel_trace.csv' -delete
-tail -3 "$out/conv_per_launch.txt"
-head -12 "$out/kernel_stats.csv" | cut -c1-140
+tail -1 "$out/conv_per_launch.txt"
+python3 - "$out/kernel_stats.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(int(r["TotalDurationNs"]) for r in rows)
+print(f"GPU time per evaluation (100 evaluations + set-up in the trace): {tot / 100 / 1e6:.3f} ms")
+for r in rows[:14]:
+    print(f"  {int(r['TotalDurationNs']) / 100 / 1e3:8.1f} us/eval  {int(r['Calls']):5d} calls  {r['Name'][:100]}")
+PY

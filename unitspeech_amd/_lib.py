@@ -55,6 +55,7 @@ SIGNATURES = {
     "us_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "us_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "us_profile_read_f16": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "us_clip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "us_last_error": (C.c_char_p, [C.c_void_p]),

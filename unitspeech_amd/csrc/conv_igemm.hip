@@ -97,8 +97,13 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
                            wtap_bits = a.nphase > 1 ? a.ph_wtap[phase] : a.wtap_bits;
   const int a_oy0 = a.nphase > 1 ? (phase >> 1) : a.oy0, a_ox0 = a.nphase > 1 ? (phase & 1) : a.ox0;
   // split-K: blockIdx.x = m_tile * ksplit + ks; slice ks sums the chunks [s_lo, s_lo + S) of the ntaps * nchunk total
-  const int ks = a.ksplit > 1 ? (int)(blockIdx.x % a.ksplit) : 0;
-  const int m0 = (a.ksplit > 1 ? (int)(blockIdx.x / a.ksplit) : (int)blockIdx.x) * TM, n0 = blockIdx.y * TN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (linear id % 8 == blockIdx.x % 8 when gridDim.x is a
+  // multiple of 8), each with its own 4 MB L2.  Give XCD k the k-th contiguous eighth of the tile range instead of every eighth
+  // tile: the 3x3 taps of neighbouring tiles (the image rows above and below) are then fetched into ONE L2 instead of all eight.
+  int bx = (int)blockIdx.x;
+  if ((gridDim.x & 7u) == 0 && !(a.debug & 256)) bx = (bx & 7) * (int)(gridDim.x >> 3) + (bx >> 3);
+  const int ks = a.ksplit > 1 ? bx % a.ksplit : 0;
+  const int m0 = (a.ksplit > 1 ? bx / a.ksplit : bx) * TM, n0 = blockIdx.y * TN;
   const int Ms = a.Hs * a.Ws;
   const int nchunk = a.Cin / BK;
   const int S_all = a.ntaps * nchunk;
@@ -337,6 +342,24 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #endif
   };
+  // NSTG == 3: the DMA of chunk s+2 is issued from inside the first MFMA block of step s (it has two steps to land), so its
+  // issue slots (M0 write + buffer_load per piece) run under executing MFMAs instead of ahead of them with the matrix pipe idle
+  bool dma_pending = false;
+  int dma_buf = 0;
+  auto dma_late = [&]() {
+    if (NSTG == 3 && dma_pending) {
+#ifndef US_NO_SCHEDBAR
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (ch_n == 0) setup_tap(tap_n);
+      dma(ch_n, dma_buf);
+      if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+      dma_pending = false;
+#ifndef US_NO_SCHEDBAR
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  };
   auto mma = [&](const f32x4* fa, const f32x4* fb) {
     if (F16) {
 #pragma unroll
@@ -348,6 +371,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
           total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, total[i][j], 0, 0, 0);
           total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, total[i][j], 0, 0, 0);
+          if (i == 0 && j == 0) dma_late();
         }
       return;
     }
@@ -389,12 +413,15 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (step + 2 < S_run) {
-        if (ch_n == 0) setup_tap(tap_n);
-        dma(ch_n, cur == 0 ? 2 : cur - 1);
-        if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+        dma_pending = true;
+        dma_buf = cur == 0 ? 2 : cur - 1;
+        if (!F16 || (a.debug & 64)) dma_late();      // debug bit 64 (tools/conv_bench A/B): issue right after the barrier
       }
       const float* base = smem + cur * BUF;
+      // as in the two-buffer loop, the MFMAs of a chunk's last 16-deep step run after the next barrier, under the first
+      // fragment reads of the next chunk (8 waves x 16 ds_read_b128 queue up behind every barrier)
       load_frags(fa0, fb0, base, 0);
+      if (step > 0) { mma(fa1, fb1); step_done(); }
       load_frags(fa1, fb1, base, 1);
       mma(fa0, fb0);
       if (NS == 4) {
@@ -403,10 +430,10 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
         load_frags(fa1, fb1, base, 3);
         mma(fa0, fb0);
       }
-      mma(fa1, fb1);
-      step_done();
       cur = cur == 2 ? 0 : cur + 1;
     }
+    mma(fa1, fb1);
+    step_done();
   } else {
   for (int step = 0; step < S_run; ++step) {
     const bool has_next = step + 1 < S_run;
@@ -614,9 +641,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       }
       const int n = n0 + wn * 64 + nb * 32 + l32;
       if (hh == 0 && (l32 % seg) == 0 && n < a.Cout) {
-        double* st = a.stats + ((long long)b * kGroups + n / cg) * 2;
-        atomicAdd(st, (double)s1);
-        atomicAdd(st + 1, (double)s2);
+        stat_add(a.stats, b, n / cg, 0, blockIdx.x, (double)s1);
+        stat_add(a.stats, b, n / cg, 1, blockIdx.x, (double)s2);
       }
     }
   }
@@ -680,7 +706,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
     }
     __syncthreads();
     if (threadIdx.x < kGroups * 2)
-      atomicAdd(&a.stats[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], s_g[threadIdx.x >> 1][threadIdx.x & 1]);
+      stat_add(a.stats, b, threadIdx.x >> 1, threadIdx.x & 1, blockIdx.x, s_g[threadIdx.x >> 1][threadIdx.x & 1]);
   }
 }
 

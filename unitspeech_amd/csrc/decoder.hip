@@ -104,7 +104,8 @@ struct us_decoder {
   bool f16x3_direct = true;  // US_F16X3_DIRECT=0: direct convolutions (1x1, stride 2, transposed, non-Winograd 3x3) stay on fp32 MFMA
   long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
-  int wino_min_level = 0;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off
+  int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
+                            // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
   // saved-activation records of us_estimator_forward_train calls that have not been consumed by a backward yet, by tape id
   // (each lives in its caller's workspace; the oldest is dropped beyond kMaxTapes)
@@ -114,13 +115,15 @@ struct us_decoder {
   std::string err;
 
   // ---- sampled kernel timing (bench.py roofline leg) ----
-  struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = conv_igemm launch, 1 = whole evaluation
+  struct ProfRec { hipEvent_t a, b; double flops; int kind; int f16 = 0; };   // kind 0 = conv_igemm launch, 1 = whole evaluation
   bool prof_enabled = false;
   bool prof_active = false;           // true while the sampled evaluation is being enqueued
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_conv_ms = 0, prof_conv_flops = 0, prof_eval_ms = 0;
   long long prof_conv_launches = 0, prof_evals = 0;
+  double prof_f16_ms = 0, prof_f16_flops = 0;      // the f16x3 launches among them (flops: fp32-equivalent, 2 * M * N * K)
+  long long prof_f16_launches = 0;
   hipEvent_t prof_event() {
     if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -295,7 +298,7 @@ struct Buffers {
   float *in2, *posemb, *mlp_h, *temb, *tproj;
   std::vector<size_t> tproj_off;   // per resnet, in floats
   int tproj_ld = 0;
-  double* stats;                   // [n_gn][Bp][8][2]
+  double* stats;                   // [n_gn][Bp][8][2][kStatSlots]
   size_t stats_count = 0;
   std::vector<float*> D, P, Q, S1, S2, QKV, CAT;
   float* U0;
@@ -321,7 +324,7 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false
   reg(h->mid1); reg(h->mid2);
   for (auto& u : h->ups) { reg(u.r1); reg(u.r2); }
   b.tproj = A.alloc<float>(toff);
-  b.stats_count = (size_t)(2 * h->n_resnets + 1) * B * kGroups * 2;
+  b.stats_count = (size_t)(2 * h->n_resnets + 1) * B * kGroups * kStatStride;
   b.stats = A.alloc<double>(b.stats_count);
   b.D.assign(L, nullptr); b.P.assign(L, nullptr); b.Q.assign(L, nullptr); b.S1.assign(L, nullptr);
   b.S2.assign(L, nullptr); b.QKV.assign(L, nullptr); b.CAT.assign(L, nullptr);
@@ -384,7 +387,7 @@ struct EvalCtx {
 };
 
 double* next_stats(EvalCtx& e) {
-  double* p = e.b->stats + (size_t)(e.gn_slot++) * e.Bp * kGroups * 2;
+  double* p = e.b->stats + (size_t)(e.gn_slot++) * e.Bp * kGroups * kStatStride;
   return p;
 }
 
@@ -425,6 +428,7 @@ hipError_t run_conv(EvalCtx& e, const ConvArgs& a) {
   r.b = h->prof_event();
   r.kind = 0;
   r.flops = 2.0 * a.B * (double)a.Hs * a.Ws * a.Cout * (double)a.Cin * a.ntaps * (a.nphase > 1 ? a.nphase : 1);
+  r.f16 = a.f16 ? 1 : 0;
   (void)hipEventRecord(r.a, e.s);
   hipError_t err = launch_conv_igemm(a, e.s);
   (void)hipEventRecord(r.b, e.s);
@@ -479,6 +483,7 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
     us_decoder::ProfRec r;
     r.a = h->prof_event(); r.b = h->prof_event(); r.kind = 0;
     r.flops = 2.0 * 16 * e.Bp * (double)th * tw * N * (double)K;
+    r.f16 = a.f16 ? 1 : 0;
     (void)hipEventRecord(r.a, e.s);
     err = launch_conv_igemm(a, e.s);
     (void)hipEventRecord(r.b, e.s);
@@ -1180,7 +1185,10 @@ int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* c
     float ms = 0.f;
     if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
       return h->fail(US_EHIP, "profile event read failed (device not synchronised?)");
-    if (r.kind == 0) { h->prof_conv_ms += ms; h->prof_conv_flops += r.flops; h->prof_conv_launches++; }
+    if (r.kind == 0) {
+      h->prof_conv_ms += ms; h->prof_conv_flops += r.flops; h->prof_conv_launches++;
+      if (r.f16) { h->prof_f16_ms += ms; h->prof_f16_flops += r.flops; h->prof_f16_launches++; }
+    }
     else { h->prof_eval_ms += ms; h->prof_evals++; }
     h->prof_pool.push_back(r.a);
     h->prof_pool.push_back(r.b);
@@ -1191,7 +1199,18 @@ int us_profile_read(us_handle h, double* conv_ms, double* conv_flops, int64_t* c
   if (conv_launches) *conv_launches = h->prof_conv_launches;
   if (eval_ms) *eval_ms = h->prof_eval_ms;
   if (evals) *evals = h->prof_evals;
-  if (reset) { h->prof_conv_ms = h->prof_conv_flops = h->prof_eval_ms = 0; h->prof_conv_launches = h->prof_evals = 0; }
+  if (reset) {
+    h->prof_conv_ms = h->prof_conv_flops = h->prof_eval_ms = 0; h->prof_conv_launches = h->prof_evals = 0;
+    h->prof_f16_ms = h->prof_f16_flops = 0; h->prof_f16_launches = 0;
+  }
+  return US_OK;
+}
+
+int us_profile_read_f16(us_handle h, double* f16_ms, double* f16_flops, int64_t* f16_launches) {
+  if (!h) return US_EINVAL;
+  if (f16_ms) *f16_ms = h->prof_f16_ms;
+  if (f16_flops) *f16_flops = h->prof_f16_flops;
+  if (f16_launches) *f16_launches = h->prof_f16_launches;
   return US_OK;
 }
 

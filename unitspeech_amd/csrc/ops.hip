@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
   if (stats) {
     __syncthreads();
     if (threadIdx.x < kGroups * 2)
-      atomicAdd(&stats[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], gred[threadIdx.x >> 1][threadIdx.x & 1]);
+      stat_add(stats, b, threadIdx.x >> 1, threadIdx.x & 1, blockIdx.x, gred[threadIdx.x >> 1][threadIdx.x & 1]);
   }
 }
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     if ((tid & 63) == 0) { atomicAdd(&red[g][0], a); atomicAdd(&red[g][1], q); }
   }
   __syncthreads();
-  if (tid < kGroups * 2) atomicAdd(&stats[((long long)b * kGroups + (tid >> 1)) * 2 + (tid & 1)], red[tid >> 1][tid & 1]);
+  if (tid < kGroups * 2) stat_add(stats, b, tid >> 1, tid & 1, blockIdx.x, red[tid >> 1][tid & 1]);
 }
 
 hipError_t launch_gn_stats(const float* y, int ld, int B, int n, int C, double* stats, hipStream_t s) {
@@ -178,9 +178,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
   const double cnt = (double)n * cg;
   __shared__ float s_mean[kGroups], s_rstd[kGroups];
   if (threadIdx.x < kGroups) {
-    const double* st = a.stats + ((long long)b * kGroups + threadIdx.x) * 2;
-    double mean = st[0] / cnt;
-    double var = st[1] / cnt - mean * mean;
+    double mean = stat_read(a.stats, b, threadIdx.x, 0) / cnt;
+    double var = stat_read(a.stats, b, threadIdx.x, 1) / cnt - mean * mean;
     if (var < 0) var = 0;
     s_mean[threadIdx.x] = (float)mean;
     s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));

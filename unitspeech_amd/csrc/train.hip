@@ -324,9 +324,9 @@ hipError_t launch_colsum(const float* g, int ld, long long rows, int C, const fl
 //   gy = rstd*(dz*gamma - S1/N - xn*S2/N);  gbias_conv[c] += gy
 // ---------------------------------------------------------------------------------------------------
 struct GnStat { float mean, rstd; };
-__device__ __forceinline__ GnStat gn_stat(const double* st, double cnt) {
-  double mean = st[0] / cnt;
-  double var = st[1] / cnt - mean * mean;
+__device__ __forceinline__ GnStat gn_stat(const double* stats, long long b, int group, double cnt) {
+  double mean = stat_read(stats, b, group, 0) / cnt;
+  double var = stat_read(stats, b, group, 1) / cnt - mean * mean;
   if (var < 0) var = 0;
   GnStat r;
   r.mean = (float)mean;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   __shared__ float s_ch[2][1024];          // per-channel partial sums (C <= 1024)
   __shared__ double s_grp[kGroups][2];
   if (threadIdx.x < kGroups) {
-    GnStat st = gn_stat(a.stats + ((long long)b * kGroups + threadIdx.x) * 2, cnt);
+    GnStat st = gn_stat(a.stats, b, threadIdx.x, cnt);
     s_mean[threadIdx.x] = st.mean;
     s_rstd[threadIdx.x] = st.rstd;
     if (PASS == 2) {

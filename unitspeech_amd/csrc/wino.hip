@@ -130,9 +130,8 @@ __global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restr
   if (threadIdx.x < kGwCS) {
     const int c = c0 + threadIdx.x;
     const double cnt = (double)H * W * cg;
-    const double* st = g.stats + ((long long)b * kGroups + c / cg) * 2;
-    const double mean = st[0] / cnt;
-    double var = st[1] / cnt - mean * mean;
+    const double mean = stat_read(g.stats, b, c / cg, 0) / cnt;
+    double var = stat_read(g.stats, b, c / cg, 1) / cnt - mean * mean;
     if (var < 0) var = 0;
     const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + 1e-5));
     const float sc = rstd * g.gamma[c];
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     flush();
     __syncthreads();
     if (threadIdx.x < kGroups * 2)
-      atomicAdd(&stats[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], s_g[threadIdx.x >> 1][threadIdx.x & 1]);
+      stat_add(stats, b, threadIdx.x >> 1, threadIdx.x & 1, blockIdx.x, s_g[threadIdx.x >> 1][threadIdx.x & 1]);
   }
 }
 
