@@ -14,11 +14,13 @@ ap.add_argument("trace")
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--bp", type=int, default=3)
 ap.add_argument("--dim", type=int, default=128)
+ap.add_argument("--wino-min-level", type=int, default=1, help="levels >= this run their 3x3 convs as Winograd (US_WINO_MIN_LEVEL)")
 a = ap.parse_args()
 
 F, T, BP = 80, a.frames, a.bp
 C = [a.dim * m for m in (1, 2, 4, 8)]
 L = 4
+WMIN = a.wino_min_level
 
 
 def npx(l):
@@ -36,8 +38,8 @@ def conv(name, l_out_pixels, cin, cout, taps, wino=False):
 
 def resnet(name, l, cin, cout, first=False):
     if not first:
-        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=True)
-    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=True)
+        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=l >= WMIN)
+    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=l >= WMIN)
     if cin != cout and not first:
         conv(f"{name}.res 1x1 {cin}->{cout} L{l}", npx(l), cin, cout, 1)
 
@@ -64,7 +66,7 @@ for u in range(L - 1):
     resnet(f"ups.{u}.r2", l, co, co)
     attn(f"ups.{u}.attn", l, co)
     conv(f"ups.{u}.up 4x4s2T {co} L{l}->L{l-1} (4 phases, one launch)", npx(l), co, co, 16)
-conv("final 3x3 128->128 L0", npx(0), C[0], C[0], 9, wino=True)
+conv("final 3x3 128->128 L0", npx(0), C[0], C[0], 9, wino=0 >= WMIN)
 
 rows = [r for r in csv.DictReader(open(a.trace)) if "conv_igemm" in r["Kernel_Name"]]
 n = len(seq)

@@ -216,7 +216,7 @@ int main(int argc, char** argv) {
     for (int tm : {256, 128, 64}) {
       if (getenv("CB_TM") && atoi(getenv("CB_TM")) != tm) continue;
       if (tm == 256 && !(f16 && sh.wino != 2)) continue;
-      const int debug = debug_arg | (ab ? ab_bit : 0);
+      const int debug = debug_arg | ((ab != 0) != (getenv("CB_AB_FIRST") != nullptr) ? ab_bit : 0);
       ConvArgs a; memset(&a, 0, sizeof a);
       a.in = in; a.in_ld = sh.Cin; a.wt = w; a.bias = bias; a.out = out; a.out_ld = sh.Cout; a.zeros = zeros;
       a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;

@@ -100,10 +100,14 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (linear id % 8 == blockIdx.x % 8 when gridDim.x is a
   // multiple of 8), each with its own 4 MB L2.  Give XCD k the k-th contiguous eighth of the tile range instead of every eighth
   // tile: the 3x3 taps of neighbouring tiles (the image rows above and below) are then fetched into ONE L2 instead of all eight.
-  int bx = (int)blockIdx.x;
-  if ((gridDim.x & 7u) == 0 && !(a.debug & 256)) bx = (bx & 7) * (int)(gridDim.x >> 3) + (bx >> 3);
+  // The grid's x dimension enumerates (row tile, column tile) pairs with the column tile fastest, so the column tiles of one row
+  // tile -- which re-read the same A rows -- run back to back on the same XCD (the re-reads used to come from the Infinity Cache:
+  // 765 MB of fabric traffic per level-2 Winograd GEMM against 270 MB of operands, rocprofv3 FETCH_SIZE).
+  int bt = (int)blockIdx.x;
+  if ((gridDim.x & 7u) == 0 && !(a.debug & 256)) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
+  const int bx = bt / a.nt;
   const int ks = a.ksplit > 1 ? bx % a.ksplit : 0;
-  const int m0 = (a.ksplit > 1 ? bx / a.ksplit : bx) * TM, n0 = blockIdx.y * TN;
+  const int m0 = (a.ksplit > 1 ? bx / a.ksplit : bx) * TM, n0 = (bt - bx * a.nt) * TN;
   const int Ms = a.Hs * a.Ws;
   const int nchunk = a.Cin / BK;
   const int S_all = a.ntaps * nchunk;
@@ -641,8 +645,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       }
       const int n = n0 + wn * 64 + nb * 32 + l32;
       if (hh == 0 && (l32 % seg) == 0 && n < a.Cout) {
-        stat_add(a.stats, b, n / cg, 0, blockIdx.x, (double)s1);
-        stat_add(a.stats, b, n / cg, 1, blockIdx.x, (double)s2);
+        stat_add(a.stats, b, n / cg, 0, bx, (double)s1);
+        stat_add(a.stats, b, n / cg, 1, bx, (double)s2);
       }
     }
   }
@@ -820,7 +824,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (k > 32) k = 32;
     if (k >= 2 && k * (long long)a.B * Ms * a.Cout <= a.splitk_ws_floats) a.ksplit = (int)k;
   }
-  dim3 grid(mt * a.ksplit, nt, a.B * (a.nphase > 1 ? a.nphase : 1));
+  a.nt = nt;
+  dim3 grid(mt * a.ksplit * nt, 1, a.B * (a.nphase > 1 ? a.nphase : 1));
   const size_t lds = lds_bytes(a.bk, tm);
   if (a.f16 == 2) {
     if (tm == 256) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 4, 3, true>), grid, dim3(512), lds_bytes(32, 256, 3), s, a);

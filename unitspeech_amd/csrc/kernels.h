@@ -61,6 +61,7 @@ struct ConvArgs {
   int bk;                // 16 or 32: channel chunk the weights were packed for
   int tm;                // rows per workgroup: 128, 64 or 0 = choose from the grid size
   int ksplit;            // set by the launcher: K slices per tile (1 = single pass)
+  int nt;                // set by the launcher: column tiles (grid x = row tiles * ksplit * nt, column tile fastest)
   int f16;               // f16x3 GEMM (bk = 32): `wt` holds two interleaved fp16 planes per value; 1: so does `in` (Winograd domain),
                          // 2: `in` is a plain fp32 tensor that the kernel splits on the fly (direct convolutions)
   int wino_out;          // 1: `in` = V [16][B][Hs][Ws][Cin], `wt` = 16 matrices wt_bstride apart; Winograd output transform in the kernel
