@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--check", type=int, default=0, help="compare the first K losses with the CPU oracle (slow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=2, help="iterations of the CPU oracle (torch autograd + Adam) timed")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured HIP graph (unitspeech_amd.graph)")
     ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
                     help="fused: HIP clip+Adam in 3 launches (unitspeech_amd.FusedAdam); torch: clip_grad_norm_ + torch.optim.Adam")
     a = ap.parse_args()
@@ -52,10 +53,19 @@ def main():
     dv = lambda t: t.to(dev)
     cond_x_d, y_d, y_mask_d, y_len_d, attn_d, spk_d = map(dv, (cond_x, y, y_mask, y_lengths, attn, spk))
 
+    random.seed(0); torch.manual_seed(0)
+    graph = None
+    if not a.no_graph:
+        from unitspeech_amd.graph import FineTuneGraph
+        graph = FineTuneGraph(model, spk_d, 1, a.segment, cfg.n_feats)
+
     def step():
-        loss = model.fine_tune(cond_x_d, y_d, y_mask_d, y_len_d, L, attn_d, spk_d, a.segment, cfg.n_feats)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
+        if graph is not None:
+            loss = graph.step(cond_x_d, y_d, y_len_d, attn_d)
+        else:
+            loss = model.fine_tune(cond_x_d, y_d, y_mask_d, y_len_d, L, attn_d, spk_d, a.segment, cfg.n_feats)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
         if fused:
             opt.step(max_norm=1)
         else:
@@ -63,7 +73,6 @@ def main():
             opt.step()
         return loss
 
-    random.seed(0); torch.manual_seed(0)
     losses = []
     for _ in range(a.warmup):
         losses.append(step().item())
@@ -80,7 +89,7 @@ def main():
     res = {"metric": "fine-tune seconds/iteration (B=1, 176-frame crop, fwd+bwd+clip+Adam)", "value": dt, "unit": "s/iter",
            "higher_is_better": False, "n_gpus": 1, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"finetune.py:131-165 inner loop, B=1, {a.segment}-frame crops of a {L}-frame utterance, full-size decoder, "
-                                  f"Adam lr 2e-5, clip 1.0", "optimizer": a.optimizer},
+                                  f"Adam lr 2e-5, clip 1.0", "optimizer": a.optimizer, "launch": "eager" if graph is None else "hip graph"},
            "iters": a.iters, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": loss.item(),
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                         "flops_per_iteration": step_flops,

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--n_iters", type=int, default=500, help="Number of fine-tuning iterations.")
     ap.add_argument("--learning_rate", type=float, default=2e-5, help="Learning rate of the optimizer during fine-tuning.")
     ap.add_argument("--torch_optimizer", action="store_true", help="clip_grad_norm_ + torch.optim.Adam instead of the HIP clip+Adam")
+    ap.add_argument("--no_graph", action="store_true", help="launch every kernel of an iteration eagerly instead of replaying one captured HIP graph")
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--reference_root", type=str, default=None)
     ap.add_argument("--out_dir", type=str, default="checkpoints/inference")
@@ -81,11 +82,18 @@ def main():
     x_mask = torch.ones(1, 1, cond_x.shape[-1], device=device)
     attn = generate_path(duration, (x_mask.unsqueeze(-1) * mel_mask.unsqueeze(2)).squeeze(1))
 
+    graph = None
+    if not args.no_graph:
+        from unitspeech_amd.graph import FineTuneGraph
+        graph = FineTuneGraph(decoder, spk_emb, mel.shape[0], segment, cfg.n_feats)    # forward + backward of an iteration as one HIP graph
     t0 = time.perf_counter()
     for it in range(args.n_iters):                                                           # finetune.py:131-165
-        loss = decoder.fine_tune(cond_x, mel, mel_mask, mel_lengths, mel.shape[-1], attn, spk_emb, segment, cfg.n_feats)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
+        if graph is not None:
+            loss = graph.step(cond_x, mel, mel_lengths, attn)
+        else:
+            loss = decoder.fine_tune(cond_x, mel, mel_mask, mel_lengths, mel.shape[-1], attn, spk_emb, segment, cfg.n_feats)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
         if args.torch_optimizer:
             torch.nn.utils.clip_grad_norm_(decoder.parameters(), 1)
             opt.step()

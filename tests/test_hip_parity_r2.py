@@ -348,3 +348,47 @@ def test_invalidate_weights_after_in_place_data_write():
         b = model.estimator(*args)
     diff = (b - a) * inp["mask"].to(DEV)
     assert (diff - inp["mask"].to(DEV)).abs().max().item() <= 1e-6     # final_conv bias + 1 on every valid frame
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the fine-tune iteration as one HIP graph: same loss trajectory and parameters as the eager launches
+# ---------------------------------------------------------------------------------------------------------------
+def test_finetune_graph_replay_matches_eager_iterations():
+    import random
+    from unitspeech_amd import FusedAdam
+    from unitspeech_amd.graph import FineTuneGraph
+    from unitspeech_amd.util import generate_path, sequence_mask
+    gen = np.random.Generator(np.random.Philox(key=321))
+    L, Lu, seg = 96, 32, 32
+    y = torch.from_numpy(gen.standard_normal((1, 80, L), dtype=np.float32)).clamp(-1, 1).to(DEV)
+    cond_x = torch.from_numpy(gen.standard_normal((1, 80, Lu), dtype=np.float32) * 0.5).to(DEV)
+    y_len = torch.LongTensor([L]).to(DEV)
+    y_mask = sequence_mask(y_len, L).unsqueeze(1).float()
+    attn = generate_path(torch.full((1, Lu), 3.0, device=DEV), (torch.ones(1, 1, Lu, device=DEV).unsqueeze(-1) * y_mask.unsqueeze(2)).squeeze(1))
+    spk = G(synthetic_inputs(TINY, 1, 8, seed=12))["spk_emb"].to(DEV)
+
+    def run(use_graph, iters=5):
+        model = make_model(TINY).train()
+        opt = FusedAdam(model.parameters(), lr=1e-3)         # large enough that a missed weight re-pack would show in the next loss
+        random.seed(7); torch.manual_seed(7)
+        graph = FineTuneGraph(model, spk, 1, seg, 80) if use_graph else None
+        losses = []
+        for _ in range(iters):
+            if graph is not None:
+                loss = graph.step(cond_x, y, y_len, attn)
+            else:
+                loss = model.fine_tune(cond_x, y, y_mask, y_len, L, attn, spk, seg, 80)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+            opt.step(max_norm=1)
+            losses.append(loss.item())
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    print(f"\neager losses {le}\ngraph losses {lg}")
+    assert len(set(le)) == len(le)                            # the iterations differ (new crop, new noise, new weights)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a))           # fp32 atomics order is the only difference
+    for k in pe:
+        assert (pe[k] - pg[k]).abs().max() <= 2e-5, k          # 2 % of one Adam step (lr = 1e-3): elements whose gradient is ~eps

@@ -24,6 +24,7 @@ SIGNATURES = {
     "us_decoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(us_config)]),
     "us_decoder_destroy": (C.c_int, [C.c_void_p]),
     "us_decoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    "us_decoder_flush_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "us_decoder_num_weights": (C.c_int, [C.c_void_p]),
     "us_decoder_num_loaded": (C.c_int, [C.c_void_p]),
     "us_decoder_weight_key": (C.c_char_p, [C.c_void_p, C.c_int]),

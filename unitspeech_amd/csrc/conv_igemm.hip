@@ -878,34 +878,41 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __
   }
 }
 
-// f16x3 form (bk = 32): dst (halves) [tap][Cin/32][Cout][4 groups x (8 hi | 8 lo)], same bytes and row structure as the fp32 pack
-__global__ void pack_conv_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin, int KH, int KW,
-                                            int oihw) {
-  const long long total = (long long)KH * KW * Cout * Cin;
+// f16x3 form (bk = 32): dst (halves) [tap][Cin/32][Cout][4 groups x (8 hi | 8 lo)], same bytes and row structure as the fp32 pack.
+// One thread = one 32-byte piece (8 input channels of one (tap, output channel)): two 16-byte stores.
+typedef _Float16 half8p __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void pack_conv_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin,
+                                                                   int KH, int KW, int oihw) {
+  const long long total = (long long)KH * KW * Cout * (Cin / 8);
   const int nchunk = Cin / 32;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int k = (int)(i % 32);
-    long long t = i / 32;
-    int co = (int)(t % Cout); t /= Cout;
-    int ch = (int)(t % nchunk);
-    int tap = (int)(t / nchunk);
-    int ci = ch * 32 + k;
-    int ky = tap / KW, kx = tap % KW;
-    long long si = oihw ? (((long long)co * Cin + ci) * KH + ky) * KW + kx
-                        : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
-    const float c = fminf(fmaxf(src[si], -65504.f), 65504.f);
-    const _Float16 h = (_Float16)c;
-    const long long o = (i - k) * 2 + (k / 8) * 16 + k % 8;
-    dst[o] = h;
-    dst[o + 8] = (_Float16)fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+    const int g4 = (int)(i & 3);
+    long long t = i >> 2;
+    const int co = (int)(t % Cout); t /= Cout;
+    const int ch = (int)(t % nchunk);
+    const int tap = (int)(t / nchunk);
+    const int ky = tap / KW, kx = tap % KW;
+    half8p hi, lo;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int ci = ch * 32 + g4 * 8 + kk;
+      const long long si = oihw ? (((long long)co * Cin + ci) * KH + ky) * KW + kx : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
+      const float c = fminf(fmaxf(src[si], -65504.f), 65504.f);
+      const _Float16 h = (_Float16)c;
+      hi[kk] = h;
+      lo[kk] = (_Float16)fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+    }
+    _Float16* d = dst + i * 16;
+    *reinterpret_cast<half8p*>(d) = hi;
+    *reinterpret_cast<half8p*>(d + 8) = lo;
   }
 }
 
 hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s) {
   if (Cin % 32 != 0) return hipErrorInvalidValue;
-  long long total = (long long)KH * KW * Cout * Cin;
+  long long total = (long long)KH * KW * Cout * (Cin / 8);
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_conv_weight_f16_kernel, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), Cout, Cin, KH, KW,
                      oihw ? 1 : 0);
   return hipGetLastError();

@@ -107,6 +107,17 @@ struct us_decoder {
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
                             // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
+  // RAW tensors (biases, GroupNorm affine, MLP weights: ~130 small ones) are copied by ONE table-driven launch per weight sync
+  // instead of one hipMemcpyAsync each (fine-tuning re-loads every tensor after every optimiser step)
+  std::vector<CopyEnt> pending_copies;
+  CopyEnt* copy_tab_dev = nullptr;
+  CopyEnt* copy_tab_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring
+  static constexpr int kCaptureTabs = 16;
+  CopyEnt* copy_tab_capture[kCaptureTabs] = {};    // write-once staging for uploads recorded into a HIP graph (no allocation is legal
+  int copy_tab_capture_used = 0;                    // while a stream captures): one per captured weight sync
+  hipEvent_t copy_tab_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int copy_tab_i = 0;
+  size_t copy_tab_cap = 0;
   // saved-activation records of us_estimator_forward_train calls that have not been consumed by a backward yet, by tape id
   // (each lives in its caller's workspace; the oldest is dropped beyond kMaxTapes)
   std::map<uint64_t, std::shared_ptr<void>> tapes;
@@ -267,6 +278,9 @@ struct us_decoder {
 };
 
 namespace {
+
+// enqueue the deferred RAW-tensor copies (us_decoder_load_weight) as one launch; called by every entry point that computes
+int flush_copies(us_decoder* h, hipStream_t st);
 
 #define US_HIP(h, expr)                                                                              \
   do {                                                                                               \
@@ -810,9 +824,38 @@ inline hipError_t compute_time_block(EvalCtx& e, TimeBlock& tb, const float* coe
 
 #include "train_host.inc"
 
+int flush_copies(us_decoder* h, hipStream_t st) {
+  const size_t n = h->pending_copies.size();
+  if (n == 0) return US_OK;
+  if (n > h->copy_tab_cap) return h->fail(US_EINVAL, "internal: copy table overflow");
+  const int slot = h->copy_tab_i++ & 3;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  CopyEnt* host = h->copy_tab_host[slot];
+  if (cap != hipStreamCaptureStatusNone) {
+    // a captured upload reads its host source at every replay: give it storage of its own that is never rewritten
+    if (h->copy_tab_capture_used >= us_decoder::kCaptureTabs)
+      return h->fail(US_EINVAL, "more than %d weight syncs recorded into HIP graphs with this handle", us_decoder::kCaptureTabs);
+    host = h->copy_tab_capture[h->copy_tab_capture_used++];
+  } else if (h->copy_tab_ev[slot]) {
+    (void)hipEventSynchronize(h->copy_tab_ev[slot]);      // the upload that last used this staging slot has completed
+  }
+  memcpy(host, h->pending_copies.data(), n * sizeof(CopyEnt));
+  US_HIP(h, hipMemcpyAsync(h->copy_tab_dev, host, n * sizeof(CopyEnt), hipMemcpyHostToDevice, st));
+  if (cap == hipStreamCaptureStatusNone) {
+    if (!h->copy_tab_ev[slot]) US_HIP(h, hipEventCreateWithFlags(&h->copy_tab_ev[slot], hipEventDisableTiming));
+    US_HIP(h, hipEventRecord(h->copy_tab_ev[slot], st));
+  }
+  US_HIP(h, launch_copy_table(h->copy_tab_dev, (int)n, st));
+  h->pending_copies.clear();
+  return US_OK;
+}
+
 int check_ready(us_decoder* h) {
   for (auto& s : h->slots)
     if (!s->loaded) return h->fail(US_EWEIGHTS, "weight '%s' has not been loaded", s->key.c_str());
+  if (!h->pending_copies.empty())
+    return h->fail(US_EWEIGHTS, "us_decoder_load_weight calls have not been followed by us_decoder_flush_weights");
   return US_OK;
 }
 
@@ -898,14 +941,29 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
       return US_EHIP;
     }
   }
+  h->copy_tab_cap = h->slots.size();
+  bool tab_ok = hipMalloc(reinterpret_cast<void**>(&h->copy_tab_dev), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
+  for (int i = 0; i < 4 && tab_ok; ++i)
+    tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_host[i]), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
+  for (int i = 0; i < us_decoder::kCaptureTabs && tab_ok; ++i)
+    tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_capture[i]), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
+  if (!tab_ok) { g_last_error = "allocation of the weight-copy table failed"; return US_EHIP; }
   *out = h.release();
   return US_OK;
+}
+
+int us_decoder_flush_weights(us_handle h, us_stream stream) {
+  if (!h) { g_last_error = "null argument"; return US_EINVAL; }
+  return flush_copies(h, static_cast<hipStream_t>(stream));
 }
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
   for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); }
   if (h->zeros) (void)hipFree(h->zeros);
+  if (h->copy_tab_dev) (void)hipFree(h->copy_tab_dev);
+  for (int i = 0; i < 4; ++i) { if (h->copy_tab_host[i]) (void)hipHostFree(h->copy_tab_host[i]); if (h->copy_tab_ev[i]) (void)hipEventDestroy(h->copy_tab_ev[i]); }
+  for (int i = 0; i < us_decoder::kCaptureTabs; ++i) if (h->copy_tab_capture[i]) (void)hipHostFree(h->copy_tab_capture[i]);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;
@@ -935,7 +993,14 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (s->kind) {
     case Kind::RAW:
-      US_HIP(h, hipMemcpyAsync(s->buf.p, data, s->buf.n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      // deferred: one table-driven launch for all RAW tensors at the next us_decoder_flush_weights / computing entry point.  `data`
+      // must stay valid until then (the Python host flushes at the end of every weight sync).
+      {
+        bool replaced = false;
+        for (auto& pc : h->pending_copies)
+          if (pc.dst == s->buf.p) { pc.src = data; replaced = true; break; }      // re-loaded before the flush: the later source wins
+        if (!replaced) h->pending_copies.push_back(CopyEnt{data, s->buf.p, (long long)s->buf.n});
+      }
       if (s->dg_as_1x1)
         US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk_dg, st));
       break;

@@ -168,6 +168,9 @@ hipError_t launch_pos_emb(const float* t, float* emb, int rows, int dim, float s
 // dst[r][0:n] = src[src_index ? src_index[r] : r % src_rows][0:n]   (row gather/copy into a strided destination)
 hipError_t launch_copy_rows(const float* src, int src_ld, int src_rows, float* dst, int dst_ld, int rows, int n, hipStream_t s);
 hipError_t launch_fill(float* dst, float value, int n, hipStream_t s);
+// table-driven copy of many small fp32 tensors in one launch: tab[i] = {src, dst, n} in device memory
+struct CopyEnt { const float* src; float* dst; long long n; };
+hipError_t launch_copy_table(const CopyEnt* tab_dev, int n_entries, hipStream_t s);
 // dst = src / ||src||_2 over n elements (spk_uncon normalisation, :358)
 hipError_t launch_l2_normalize(const float* src, float* dst, int n, hipStream_t s);
 

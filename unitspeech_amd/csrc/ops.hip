@@ -357,6 +357,18 @@ hipError_t launch_copy_rows(const float* src, int src_ld, int src_rows, float* d
   return hipGetLastError();
 }
 
+// one block column per table entry (blockIdx.y), grid-stride over its elements: ~130 RAW weight tensors in one launch
+__global__ __launch_bounds__(256) void copy_table_kernel(const CopyEnt* __restrict__ tab) {
+  const CopyEnt e = tab[blockIdx.y];
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < e.n; i += (long long)gridDim.x * 256) e.dst[i] = e.src[i];
+}
+
+hipError_t launch_copy_table(const CopyEnt* tab_dev, int n_entries, hipStream_t s) {
+  if (n_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(copy_table_kernel, dim3(64, n_entries), dim3(256), 0, s, tab_dev);
+  return hipGetLastError();
+}
+
 __global__ void fill_kernel(float* __restrict__ dst, float value, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = value;

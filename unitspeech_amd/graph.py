@@ -1,0 +1,64 @@
+"""The fine-tune iteration as ONE HIP graph.
+
+A speaker-adaptation iteration (finetune.py:131-165) is ~900 kernel launches of a few microseconds each on a 176-frame crop: the
+GPU work is a few milliseconds, the launch stream 13-14.  Shapes, parameter storage and workspaces never change across the 500
+iterations, so the whole `compute_loss` forward + `loss.backward()` (weight re-pack, score network forward with its tape, loss,
+backward, gradient blob) is captured once into a HIP graph (`torch.cuda.CUDAGraph`, i.e. hipGraph; the library's launches go to
+torch's current stream, which is the capture stream) and replayed per iteration.  Outside the graph stay only what depends on the
+host: the random crop (Python's `random`, as in the reference) and the optimiser step (its bias corrections are host scalars).
+
+    g = FineTuneGraph(decoder, spk_emb, batch=1, segment_size=176)
+    for _ in range(n_iters):
+        loss = g.step(cond_x, y, y_lengths, attn)       # == decoder.fine_tune(...) + loss.backward()
+        optimizer.step(max_norm=1)
+
+The gaussian draws inside (`torch.rand` for t, `torch.randn` for z) use torch's graph-safe Philox bookkeeping, so the stream of
+random numbers, hence the loss trajectory, is the eager one.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class FineTuneGraph:
+    def __init__(self, decoder, spk_emb: torch.Tensor, batch: int, segment_size: int, n_feats: int = None, warmup: int = 2):
+        dev = next(decoder.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("FineTuneGraph needs the decoder on a ROCm device")
+        self.decoder = decoder
+        self.n_feats = n_feats if n_feats is not None else decoder.n_feats
+        self.segment_size = int(segment_size)
+        self.spk = spk_emb.detach().to(dev, torch.float32).contiguous()
+        B, F, S = int(batch), self.n_feats, self.segment_size
+        # static inputs of the graph: `fine_tune_segment` writes the crop straight into them
+        self.y = torch.zeros(B, F, S, device=dev)
+        self.mask = torch.ones(B, 1, S, device=dev)
+        self.cond = torch.zeros(B, F, S, device=dev)
+        self.params = [p for p in decoder.parameters() if p.requires_grad]
+        # warm-up on a side stream, as stream capture requires (allocator pools, lazy initialisation, kernel module loads)
+        gen_state = torch.cuda.get_rng_state(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                for p in self.params:
+                    p.grad = None
+                loss, _ = decoder.compute_loss(self.y, self.mask, self.cond, spk_emb=self.spk)
+                loss.backward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        torch.cuda.set_rng_state(gen_state, dev)          # the warm-up must not consume the training run's random numbers
+        for p in self.params:
+            p.grad = None
+        decoder.invalidate_weights()                       # the captured graph re-packs EVERY weight: parameters change every replay
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            loss, _ = decoder.compute_loss(self.y, self.mask, self.cond, spk_emb=self.spk)
+            loss.backward()
+        self.loss = loss.detach()
+
+    def step(self, cond_x, y, y_lengths, attn) -> torch.Tensor:
+        """One `fine_tune` call plus `loss.backward()`: gradients land in `p.grad` (static tensors), returns the loss (static)."""
+        self.decoder.fine_tune_segment(cond_x, y, y_lengths, attn, self.segment_size, self.n_feats, out=(self.y, self.mask, self.cond))
+        self.graph.replay()
+        return self.loss

@@ -162,6 +162,7 @@ class _Engine:
         with torch.cuda.device(device):
             stream = _stream()
             load = self.lib.us_decoder_load_weight
+            keep = []                    # sources of deferred copies stay alive until the flush below has been enqueued
             for key, t in named_tensors:
                 tag = (t.data_ptr(), t._version, t.device)
                 if self.versions.get(key) == tag:
@@ -178,7 +179,10 @@ class _Engine:
                 if rc != 0:
                     _lib.check(rc, self.handle, f"load_weight({key})")
                 self.versions[key] = tag
-                del src   # stream-ordered: the caching allocator keeps the block alive for queued work on this stream
+                keep.append(src)
+            if keep:
+                _lib.check(self.lib.us_decoder_flush_weights(self.handle, stream), self.handle, "us_decoder_flush_weights")
+            del keep      # stream-ordered: the caching allocator keeps freed blocks intact for work already queued on this stream
 
     def invalidate(self, keys=None):
         """Forget what has been uploaded (all keys, or the given ones): the next call re-packs them.  Needed after in-place
@@ -619,12 +623,13 @@ class UnitSpeech(BaseModule):
         t = torch.rand(x0.shape[0], dtype=x0.dtype, device=x0.device, requires_grad=False).clamp_(offset, 1.0 - offset)
         return self.loss_t(x0, mask, cond, t, spk_emb)
 
-    def fine_tune(self, cond_x, y, y_mask, y_lengths, y_max_length, attn, spk_emb, segment_size, n_feats):
-        """`fine_tune`, unitspeech/unitspeech.py:452-493.  Per item one window of `segment_size` frames: the offset comes from
-        Python's `random.choice(range(0, y_length - segment_size))` exactly as in the reference (:458-462, same generator
-        consumption); `us_finetune_segment` then crops y, aligns the unit-encoder output to the window (attn_cut^T cond_x, masked)
-        and builds the window mask in one pass -- items shorter than the window are zero-extended, so no padded copies of y /
-        y_mask are made (:453-456)."""
+    def fine_tune_segment(self, cond_x, y, y_lengths, attn, segment_size, n_feats, out=None):
+        """The segment selection of `fine_tune` (unitspeech/unitspeech.py:452-486) on its own: per item one window of
+        `segment_size` frames whose offset comes from Python's `random.choice(range(0, y_length - segment_size))` exactly as in the
+        reference (:458-462, same generator consumption); `us_finetune_segment` then crops y, aligns the unit-encoder output to the
+        window (attn_cut^T cond_x, masked) and builds the window mask in one pass -- items shorter than the window are
+        zero-extended, so no padded copies of y / y_mask are made (:453-456).  Returns (y_seg, seg_mask, cond_y); `out` = three
+        preallocated tensors to fill instead (the static inputs of a captured training graph, `unitspeech_amd.graph`)."""
         dev = y.device
         B, Ly = y.shape[0], y.shape[-1]
         lens = [int(v) for v in y_lengths.cpu().tolist()]
@@ -636,15 +641,26 @@ class UnitSpeech(BaseModule):
         if tuple(attn.shape) != (B, Lu, Ly) or tuple(cond_x.shape) != (B, n_feats, Lu) or y.shape[1] != n_feats:
             raise ValueError(f"fine_tune: cond_x {tuple(cond_x.shape)}, y {tuple(y.shape)}, attn {tuple(attn.shape)} do not fit together")
         meta = torch.tensor([starts, counts], dtype=torch.int64).to(dev)
-        y_seg = torch.empty(B, n_feats, segment_size, dtype=torch.float32, device=dev)
-        cond_y = torch.empty_like(y_seg)
-        seg_mask = torch.empty(B, 1, segment_size, dtype=torch.float32, device=dev)
+        if out is None:
+            y_seg = torch.empty(B, n_feats, segment_size, dtype=torch.float32, device=dev)
+            cond_y = torch.empty_like(y_seg)
+            seg_mask = torch.empty(B, 1, segment_size, dtype=torch.float32, device=dev)
+        else:
+            y_seg, seg_mask, cond_y = out
+            if tuple(y_seg.shape) != (B, n_feats, segment_size) or tuple(cond_y.shape) != tuple(y_seg.shape) or \
+                    tuple(seg_mask.shape) != (B, 1, segment_size):
+                raise ValueError("fine_tune_segment: `out` tensors have the wrong shapes")
         cx, yy, at = _f32c(cond_x, dev), _f32c(y, dev), _f32c(attn, dev)
         with torch.cuda.device(dev):
             rc = _lib.load().us_finetune_segment(_dev_ptr(cx), _dev_ptr(yy), _dev_ptr(at), _dev_ptr(meta[0]), _dev_ptr(meta[1]),
                                                  _dev_ptr(y_seg), _dev_ptr(cond_y), _dev_ptr(seg_mask), B, n_feats, Lu, Ly,
                                                  int(segment_size), _stream())
         _lib.check(rc, None, "us_finetune_segment")
+        return y_seg, seg_mask, cond_y
+
+    def fine_tune(self, cond_x, y, y_mask, y_lengths, y_max_length, attn, spk_emb, segment_size, n_feats):
+        """`fine_tune`, unitspeech/unitspeech.py:452-493: random window per item (`fine_tune_segment`), then the diffusion loss."""
+        y_seg, seg_mask, cond_y = self.fine_tune_segment(cond_x, y, y_lengths, attn, segment_size, n_feats)
         diff_loss, _ = self.compute_loss(y_seg, seg_mask, cond_y, spk_emb=spk_emb)
         return diff_loss
 
