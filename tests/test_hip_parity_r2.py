@@ -391,4 +391,7 @@ def test_finetune_graph_replay_matches_eager_iterations():
     for a, b in zip(le, lg):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(a))           # fp32 atomics order is the only difference
     for k in pe:
-        assert (pe[k] - pg[k]).abs().max() <= 2e-5, k          # 2 % of one Adam step (lr = 1e-3): elements whose gradient is ~eps
+        d = (pe[k] - pg[k]).abs()
+        # Adam divides by sqrt(v): where a gradient is itself rounding noise (fp32 atomics order in the weight gradients) the update is
+        # +-lr in either run; such elements may differ by a fraction of a step (lr = 1e-3), the tensors as a whole may not
+        assert d.max() <= 2e-4 and d.mean() <= 1e-7, (k, d.max().item(), d.mean().item())
