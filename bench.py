@@ -169,7 +169,7 @@ class HipWorkload:
 def pmc_traffic():
     """HBM bytes per conv launch from the committed counter summary (separate rocprofv3 --pmc passes, tools/pmc_traffic.py), with
     the commit it was measured at: a constant of that commit, not of the run that prints it."""
-    for name in ("r02_pmc_summary.json", "pmc_traffic.json"):
+    for name in ("r02_pmc_summary.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:

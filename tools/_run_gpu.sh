@@ -1,4 +1,9 @@
 set -u
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/r2_gpu_tests_5.log 2>&1; tail -4 gpurun_out/r2_gpu_tests_5.log
-python bench_finetune.py --iters 40 --no-cpu-baseline 2>/dev/null > gpurun_out/r2_bench_finetune_graph.json; cut -c1-120 gpurun_out/r2_bench_finetune_graph.json
-python bench_finetune.py --iters 40 --no-cpu-baseline --no-graph 2>/dev/null > gpurun_out/r2_bench_finetune_eager.json; cut -c1-120 gpurun_out/r2_bench_finetune_eager.json
+t0=$(date +%s)
+python bench.py > gpurun_out/r02_bench_B1.json 2> gpurun_out/r02_bench_B1.err; echo "default bench: $(( $(date +%s) - t0 )) s"; cut -c1-120 gpurun_out/r02_bench_B1.json
+python bench.py --config 64x1 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_B64.json 2>/dev/null; cut -c1-120 gpurun_out/r02_bench_B64.json
+python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_B8.json 2>/dev/null; cut -c1-120 gpurun_out/r02_bench_B8.json
+python bench_finetune.py --iters 50 > gpurun_out/r02_bench_finetune.json 2>/dev/null; cut -c1-120 gpurun_out/r02_bench_finetune.json
+python bench_pretrain.py --iters 5 > gpurun_out/r02_bench_pretrain.json 2>/dev/null; cut -c1-200 gpurun_out/r02_bench_pretrain.json
+timeout -k 10 400 tools/profile_bench.sh r02_prof < /dev/null | tail -3
+timeout -k 10 600 tools/pmc_collect.sh r02_pmc < /dev/null | tail -4
