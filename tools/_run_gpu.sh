@@ -1,9 +1,9 @@
 set -u
-t0=$(date +%s)
-python bench.py > gpurun_out/r02_bench_B1.json 2> gpurun_out/r02_bench_B1.err; echo "default bench: $(( $(date +%s) - t0 )) s"; cut -c1-120 gpurun_out/r02_bench_B1.json
-python bench.py --config 64x1 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_B64.json 2>/dev/null; cut -c1-120 gpurun_out/r02_bench_B64.json
-python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_B8.json 2>/dev/null; cut -c1-120 gpurun_out/r02_bench_B8.json
-python bench_finetune.py --iters 50 > gpurun_out/r02_bench_finetune.json 2>/dev/null; cut -c1-120 gpurun_out/r02_bench_finetune.json
-python bench_pretrain.py --iters 5 > gpurun_out/r02_bench_pretrain.json 2>/dev/null; cut -c1-200 gpurun_out/r02_bench_pretrain.json
-timeout -k 10 400 tools/profile_bench.sh r02_prof < /dev/null | tail -3
-timeout -k 10 600 tools/pmc_collect.sh r02_pmc < /dev/null | tail -4
+hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/conv_bench || exit 1
+for f in "F1 fused 256" "F1 fused 512" "F2" "F3" "F0"; do
+  CB_ONLY="$f" CB_F16=1 CB_AB=128 CB_TM=64 CB_STATS=1 CB_COLD=1 /tmp/conv_bench 9
+  CB_ONLY="$f" CB_F16=1 CB_AB=128 CB_AB_FIRST=1 CB_TM=64 CB_STATS=1 CB_COLD=1 /tmp/conv_bench 9
+done
+timeout -k 10 300 python -m pytest tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | cut -c1-120
+python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | cut -c1-120

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int RPI = 64 / CPR;      // rows covered by one wave-wide DMA instruction
   constexpr int IA = TM / RPI / NW;  // DMA instructions per wave for the A tile
   constexpr int IB = TN / RPI / NW;  // ... for the B tile
-  static_assert(NSTG == 2 || (NSTG == 3 && !WINO), "three operand buffers: plain GEMM form only");
+  static_assert(NSTG == 2 || NSTG == 3, "two or three operand buffers");
   constexpr int SWZ_DIV = 64 / BK;   // rows per 256-byte bank window
   constexpr int BUF = (TM + TN) * BK;  // floats per LDS buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -285,7 +285,10 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
   if (NSTG == 3) {
     if (S_run > 1) {
-      if (ch_n == 0) setup_tap(tap_n);
+      if (ch_n == 0) {
+        if (WINO) setup_freq(tap_n);
+        else setup_tap(tap_n);
+      }
       dma(ch_n, 1);
       if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
     }
@@ -355,7 +358,10 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #ifndef US_NO_SCHEDBAR
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (ch_n == 0) setup_tap(tap_n);
+      if (ch_n == 0) {
+        if (WINO) setup_freq(tap_n);
+        else setup_tap(tap_n);
+      }
       dma(ch_n, dma_buf);
       if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
       dma_pending = false;
@@ -424,8 +430,23 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       const float* base = smem + cur * BUF;
       // as in the two-buffer loop, the MFMAs of a chunk's last 16-deep step run after the next barrier, under the first
       // fragment reads of the next chunk (8 waves x 16 ds_read_b128 queue up behind every barrier)
+      if (WINO && F16) {
+        // fused output transform: the four Y accumulators leave no room for a second fragment set (256 VGPRs at two waves per
+        // SIMD), so the two 16-deep steps of a chunk run one after the other; the co-resident workgroups cover the read latency
+        load_frags(fa0, fb0, base, 0);
+        mma(fa0, fb0);
+        load_frags(fa0, fb0, base, 1);
+        mma(fa0, fb0);
+        if ((step + 1) % nchunk == 0) fold(step / nchunk);
+        cur = cur == 2 ? 0 : cur + 1;
+        continue;
+      }
       load_frags(fa0, fb0, base, 0);
-      if (step > 0) { mma(fa1, fb1); step_done(); }
+      if (step > 0) {
+        mma(fa1, fb1);
+        step_done();
+        if (WINO && step % nchunk == 0) fold(step / nchunk - 1);     // ... which completed a frequency
+      }
       load_frags(fa1, fb1, base, 1);
       mma(fa0, fb0);
       if (NS == 4) {
@@ -436,8 +457,11 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       }
       cur = cur == 2 ? 0 : cur + 1;
     }
-    mma(fa1, fb1);
-    step_done();
+    if (!(WINO && F16)) {
+      mma(fa1, fb1);
+      step_done();
+      if (WINO) fold(15);
+    }
   } else {
   for (int step = 0; step < S_run; ++step) {
     const bool has_next = step + 1 < S_run;
@@ -736,6 +760,7 @@ hipError_t conv_igemm_init() {
   if ((e = set_attr<32, 32, false, true, 2, 2, true>()) != hipSuccess) return e;
   if ((e = set_attr<32, 32, false, true>()) != hipSuccess) return e;
   if ((e = set_attr<32, 32, true, true>()) != hipSuccess) return e;
+  if ((e = set_attr<32, 32, true, true, 2, 3>()) != hipSuccess) return e;
   return set_attr<16, 32, true>();
 }
 
@@ -832,7 +857,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     else if (tm == 128) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 2, 2, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<32, 32, false, true, 2, 2, true>), grid, dim3(256), lds, s, a);
   } else if (a.f16) {
-    if (a.wino_out) hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true, true>), grid, dim3(256), lds, s, a);
+    if (a.wino_out && !(a.debug & 128)) hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true, true, 2, 3>), grid, dim3(256), lds_bytes(32, 64, 3), s, a);
+    else if (a.wino_out) hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true, true>), grid, dim3(256), lds, s, a);
     else if (tm == 256) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 4, 3>), grid, dim3(512), lds_bytes(32, 256, 3), s, a);
     else if (tm == 128) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<32, 32, false, true>), grid, dim3(256), lds, s, a);
