@@ -62,6 +62,24 @@ __global__ void mfma_f16_peak_kernel(float* out, int iters, unsigned long long* 
   if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+__global__ void mfma_f16_16x16_peak_kernel(float* out, int iters, unsigned long long* clk) {
+  f32x4c a[8];
+  for (int i = 0; i < 8; ++i) a[i] = f32x4c{0.f, 0.f, 0.f, 0.f};
+  half8v x, y;
+  for (int k = 0; k < 8; ++k) { x[k] = (_Float16)(0.37f * ((threadIdx.x * 7 + k * 13) % 29) - 5.f); y[k] = (_Float16)(0.11f * ((threadIdx.x * 3 + k * 5 + blockIdx.x) % 31) - 1.7f); }
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16((j & 1) ? x : y, (j & 2) ? x : y, a[j], 0, 0, 0);
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int j = 0; j < 8; ++j) s += a[j][0] + a[j][1] + a[j][2] + a[j][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
 // Structural calibration: the conv kernel's inner-loop skeleton (TM=64 variant: 2 accumulators, 32 MFMAs per step) with
 // its ingredients switched on one at a time.  FLAGS: 1 = barrier per step, 2 = 12 ds_read_b128 per step, 4 = 6 LDS-DMA
 // pieces per step (double-buffered like the real kernel).
@@ -149,6 +167,19 @@ static void calibrate() {
     unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
     double fl = (double)blocks * 4 * iters * 4 * 32768.0;
     printf("calibration: pure MFMA f16 32x32x16 stream, %d wave(s)/SIMD: %.1f TFLOP/s (= %.1f fp32-equivalent as f16x3), shader clock %.3f GHz\n",
+           wps, fl / ms / 1e9, fl / ms / 1e9 / 3, (double)h[0] / (double)h[1] * 0.1);
+  }
+  for (int wps : {1, 2}) {
+    int blocks = 256 * wps, iters = 20000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_f16_16x16_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, clk);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(mfma_f16_16x16_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, clk);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+    double fl = (double)blocks * 4 * iters * 8 * 16384.0;
+    printf("calibration: pure MFMA f16 16x16x32 stream, %d wave(s)/SIMD: %.1f TFLOP/s (= %.1f fp32-equivalent as f16x3), shader clock %.3f GHz\n",
            wps, fl / ms / 1e9, fl / ms / 1e9 / 3, (double)h[0] / (double)h[1] * 0.1);
   }
   for (int wps : {1, 2, 4}) {
