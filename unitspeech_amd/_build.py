@@ -34,7 +34,19 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link the shared library; returns its path."""
+    """Compile every HIP source for gfx950 and link the shared library; returns its path.  Serialised across processes by a
+    lock file: the N ranks of a multi-GPU launch all come through here and must not rebuild the same objects side by side."""
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     cc = _hipcc()
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     objdir = os.path.join(HERE, "build")
