@@ -69,3 +69,21 @@ def test_host_step_coefficients_bit_exact_vs_oracle(n):
     got = m._step_coefficients(n)
     ref = O.step_coefficients(n, 0.05, 20.0)
     np.testing.assert_array_equal(got.numpy(), ref.numpy())
+
+
+def test_f16x3_split_gemm_is_at_fp32_accuracy():
+    """The arithmetic the f16x3 kernels implement (two fp16 planes per operand, three products, fp32 accumulation), emulated in NumPy:
+    its error against fp64 is the fp32 sgemm's, also with operands spanning 0.01 .. 30 in magnitude."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("f16x3_emulation", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "tools", "f16x3_emulation.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for K in (128, 1152):
+        e32, e16 = m.errors(K)
+        assert e16 <= 1.15 * e32 and e16 <= 5e-7, (K, e32, e16)
+    # the representation alone: 22 significant bits
+    x = np.random.default_rng(1).standard_normal(10000).astype(np.float32) * 100
+    hi, lo = m.split16(x)
+    assert np.abs((hi.astype(np.float64) + lo.astype(np.float64) / 2048) - x).max() <= np.abs(x).max() * 2.0 ** -22

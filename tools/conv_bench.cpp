@@ -237,8 +237,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&in, n_in * 4)); CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&w, n_w * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
     CK(launch_fill_normal(in, n_in, 1, 1, 0)); CK(launch_fill_normal(w, n_w, 1, 2, 0)); CK(launch_fill_normal(bias, sh.Cout, 1, 3, 0));
     const bool f16 = getenv("CB_F16") != nullptr;
+    const bool presplit = getenv("CB_PRESPLIT") != nullptr;      // direct convolutions with a pre-split activation tensor (f16 = 1)
     if (f16) {
-      if (sh.wino) hipLaunchKernelGGL(to_f16x2_kernel, dim3(4096), dim3(256), 0, 0, in, n_in / 8);
+      if (sh.wino || presplit) hipLaunchKernelGGL(to_f16x2_kernel, dim3(4096), dim3(256), 0, 0, in, n_in / 8);
       hipLaunchKernelGGL(to_f16x2_kernel, dim3(4096), dim3(256), 0, 0, w, n_w / 8);
     }
     const int n_ab = getenv("CB_AB") ? 2 : 1;           // CB_AB=<bit>: every case also with that debug bit set, back to back
@@ -253,7 +254,7 @@ int main(int argc, char** argv) {
       a.B = sh.B; a.Hin = a.Hout = a.Hs = sh.H; a.Win = a.Wout = a.Ws = sh.W; a.Cin = sh.Cin; a.Cout = sh.Cout;
       a.ostep = 1; a.istride = 1; a.ntaps = sh.taps; a.bk = 32; a.tm = tm; a.omask_bmod = 1; a.debug = debug;
       a.splitk_ws = skws; a.splitk_ws_floats = skfl;
-      a.f16 = f16 ? (sh.wino ? 1 : 2) : 0;
+      a.f16 = f16 ? ((sh.wino || presplit) ? 1 : 2) : 0;
       static double* stats = nullptr;
       if (!stats) { CK(hipMalloc(&stats, 1 << 20)); CK(hipMemset(stats, 0, 1 << 20)); }
       if (getenv("CB_STATS") && sh.wino != 1) a.stats = stats;
