@@ -54,6 +54,9 @@ def parse(argv=None):
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--diffusion-steps", type=int, default=50)
     ap.add_argument("--micro-batch", type=int, default=0)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use cuda:0 and talk over gloo: exercises the launch / broadcast / sharding / timing path of a "
+                         "multi-GPU run on a one-GPU box (RCCL refuses two ranks on one device); the throughput it prints is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="diffusion steps timed on the host CPU")
     a = ap.parse_args(argv)
@@ -290,7 +293,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP decoder has no CPU fallback")
-    res = run_rank(a, rank, local, world)
+    if a.rehearse_on_one_gpu:
+        res = run_rank(a, rank, 0, world, backend="gloo")
+        if res is not None:
+            res["rehearsal"] = "all ranks on cuda:0 over gloo: not a scaling measurement"
+        import torch.distributed as dist
+        if world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
+    else:
+        res = run_rank(a, rank, local, world)
     if res is not None:
         print(json.dumps(res))
 
