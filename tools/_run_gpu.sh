@@ -1,7 +1,8 @@
 set -u
-for w in 1 2 3 99; do
-US_WINO_MIN_LEVEL=$w python bench_finetune.py --iters 40 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('finetune wino_min_level=$w', round(d['value']*1e3,2), 'ms/iter', d['first_losses'][:2])"
-done
-for w in 1 99; do
-US_WINO_MIN_LEVEL=$w python bench_pretrain.py --iters 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pretrain wino_min_level=$w', round(d['ms_per_step'],1), d['ms_breakdown'])"
-done
+for i in 1 2; do timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2; done
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/r02_bench_B1.json 2>/dev/null; cut -c1-110 gpurun_out/r02_bench_B1.json
+python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_B8.json 2>/dev/null; cut -c1-110 gpurun_out/r02_bench_B8.json
+python bench.py --config 64x1 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_B64.json 2>/dev/null; cut -c1-110 gpurun_out/r02_bench_B64.json
+timeout -k 10 400 tools/profile_bench.sh r02_prof < /dev/null | tail -16
+timeout -k 10 600 tools/pmc_collect.sh r02_pmc < /dev/null | tail -3
