@@ -258,12 +258,30 @@ int main(int argc, char** argv) {
       static double* stats = nullptr;
       if (!stats) { CK(hipMalloc(&stats, 1 << 20)); CK(hipMemset(stats, 0, 1 << 20)); }
       if (getenv("CB_STATS") && sh.wino != 1) a.stats = stats;
+      if (sh.wino == 1 && !getenv("CB_NO_XCDZ")) a.xcd_z = 1;
       if (sh.wino == 1) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wt_bdiv = sh.B / 16; a.splitk_ws = nullptr; }
       if (sh.wino == 2) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wino_out = 1; a.ostep = 2; a.Hout = 2 * sh.H; a.Wout = 2 * sh.W; a.splitk_ws = nullptr; }
       if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }
       else a.set_tap(0, 0, 0, 0);
+#ifdef US_STAMP
+      static unsigned long long* stamps = nullptr;
+      const size_t n_st = (size_t)1 << 22;
+      if (!stamps) CK(hipMalloc(&stamps, n_st * 8));
+      CK(hipMemset(stamps, 0, n_st * 8));
+      a.stamp_out = stamps;
+#endif
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       for (int i = 0; i < 3; ++i) CK(launch_conv_igemm(a, 0));
+#ifdef US_STAMP
+      {
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hst(n_st);
+        CK(hipMemcpy(hst.data(), stamps, n_st * 8, hipMemcpyDeviceToHost));
+        double w = 0, b = 0, bd = 0, st = 0; long long cnt = 0;
+        for (size_t i = 0; i + 3 < n_st; i += 4) if (hst[i + 3]) { w += hst[i]; b += hst[i + 1]; bd += hst[i + 2]; st += hst[i + 3]; ++cnt; }
+        if (cnt) printf("   stamps over %lld waves: per step %.0f cycles = vmcnt wait %.0f + barrier %.0f + body %.0f\n", cnt, (w + b + bd) / st, w / st, b / st, bd / st);
+      }
+#endif
       const int reps = 10;
       float ms = 0.f;
       if (getenv("CB_COLD")) {        // flush L2 / Infinity Cache with a 1 GiB fill before every timed launch

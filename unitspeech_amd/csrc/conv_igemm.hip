@@ -91,20 +91,31 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, hh = lane >> 5;
-  const int phase = a.nphase > 1 ? (int)(blockIdx.z % a.nphase) : 0;
-  const int b = a.nphase > 1 ? (int)(blockIdx.z / a.nphase) : (int)blockIdx.z;
+  // Workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest, then z), each XCD with its own 4 MB L2.
+  // Winograd-domain GEMMs (xcd_z: blockIdx.z = frequency, every frequency its own A and B): XCD k takes the k-th contiguous
+  // eighth of the WHOLE (z, x) range, i.e. whole frequencies, so that the 32 workgroups of a frequency -- which between them read
+  // each A tile nt times and each B tile mt times -- share ONE L2 (dealt by x alone they sat on all eight: 342 MB of fabric
+  // traffic per launch against 130 MB of operands, rocprofv3 FETCH_SIZE).
+  int bt = (int)blockIdx.x, bz = (int)blockIdx.z;
+  const bool xcd_z = a.xcd_z && ((gridDim.x * gridDim.z) & 7u) == 0 && !(a.debug & 256);
+  if (xcd_z) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const unsigned lp = (lin & 7u) * ((gridDim.x * gridDim.z) >> 3) + (lin >> 3);
+    bz = (int)(lp / gridDim.x);
+    bt = (int)(lp - (unsigned)bz * gridDim.x);
+  }
+  const int phase = a.nphase > 1 ? bz % a.nphase : 0;
+  const int b = a.nphase > 1 ? bz / a.nphase : bz;
   const unsigned long long dy_bits = a.nphase > 1 ? a.ph_dy[phase] : a.dy_bits, dx_bits = a.nphase > 1 ? a.ph_dx[phase] : a.dx_bits,
                            wtap_bits = a.nphase > 1 ? a.ph_wtap[phase] : a.wtap_bits;
   const int a_oy0 = a.nphase > 1 ? (phase >> 1) : a.oy0, a_ox0 = a.nphase > 1 ? (phase & 1) : a.ox0;
   // split-K: blockIdx.x = m_tile * ksplit + ks; slice ks sums the chunks [s_lo, s_lo + S) of the ntaps * nchunk total
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (linear id % 8 == blockIdx.x % 8 when gridDim.x is a
-  // multiple of 8), each with its own 4 MB L2.  Give XCD k the k-th contiguous eighth of the tile range instead of every eighth
+  // Otherwise (linear id % 8 == blockIdx.x % 8 when gridDim.x is a multiple of 8): give XCD k the k-th contiguous eighth of the tile range instead of every eighth
   // tile: the 3x3 taps of neighbouring tiles (the image rows above and below) are then fetched into ONE L2 instead of all eight.
   // The grid's x dimension enumerates (row tile, column tile) pairs with the column tile fastest, so the column tiles of one row
   // tile -- which re-read the same A rows -- run back to back on the same XCD (the re-reads used to come from the Infinity Cache:
   // 765 MB of fabric traffic per level-2 Winograd GEMM against 270 MB of operands, rocprofv3 FETCH_SIZE).
-  int bt = (int)blockIdx.x;
-  if ((gridDim.x & 7u) == 0 && !(a.debug & 256)) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
+  if (!xcd_z && (gridDim.x & 7u) == 0 && !(a.debug & 256)) bt = (bt & 7) * (int)(gridDim.x >> 3) + (bt >> 3);
   const int bx = bt / a.nt;
   const int ks = a.ksplit > 1 ? bx % a.ksplit : 0;
   const int m0 = (a.ksplit > 1 ? bx / a.ksplit : bx) * TM, n0 = (bt - bx * a.nt) * TN;
@@ -307,6 +318,13 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       // chunk (2 * kgroup + plane) of the row; lane half hh supplies channels 8 * (2 s + hh) .. + 7 of the chunk's 32
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
+#ifdef US_ABL_LDS      // timing experiment: half the fragment reads (the lo planes alias the hi planes; results are wrong)
+        if (p == 1 && !ASPLIT) {
+          for (int i = 0; i < MB; ++i) fa[i * 2 + 1] = fa[i * 2];
+          fb[1] = fb[0]; fb[3] = fb[2];
+          continue;
+        }
+#endif
         const int co = ((((2 * s_ + hh) << 1) + p) ^ sw) * 4;
         if (!ASPLIT) {
 #pragma unroll
@@ -357,6 +375,44 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // issue slots (M0 write + buffer_load per piece) run under executing MFMAs instead of ahead of them with the matrix pipe idle
   bool dma_pending = false;
   int dma_buf = 0;
+  // F16: the pieces of a chunk (IA + IB LDS-DMA instructions per wave) are spread over the step's MFMAs instead of issued back to
+  // back: eight waves issuing 48 of them at once fill the CU's one address queue, and the waves (and the MFMAs queued behind their
+  // loads) wait there (tools/conv_bench: the burst costs 15 % of the Winograd-domain GEMMs, twice as many instructions 40 %)
+#ifndef US_DMA_SPREAD
+#define US_DMA_SPREAD 1
+#endif
+  constexpr int NPIECE = IA + IB;
+  constexpr int SLOTS = 12 * MB;                       // F16 MFMAs of a wave per chunk
+  constexpr int PSTRIDE = SLOTS / NPIECE > 0 ? SLOTS / NPIECE : 1;
+  unsigned pend_ach = 0, pend_wb = 0;
+  auto dma_piece = [&](int k) {
+    if (!dma_pending) return;
+#ifndef US_NO_SCHEDBAR
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (k == 0) {
+      if (ch_n == 0) {
+        if (WINO) setup_freq(tap_n);
+        else setup_tap(tap_n);
+      }
+      pend_ach = (unsigned)ch_n * (unsigned)(BK * 4);
+      pend_wb = wtap_bytes + (unsigned)ch_n * (unsigned)a.Cout * (unsigned)(BK * 4);
+    }
+    float* As = smem + dma_buf * BUF;
+    float* Bs = As + TM * BK;
+    if (k < IA) blds16(rsrc_a, aoff[k < IA ? k : 0], pend_ach, As + (wave * IA + k) * RPI * BK);
+    else blds16(rsrc_b, boff[k < IA ? 0 : k - IA], pend_wb, Bs + (wave * IB + (k - IA)) * RPI * BK);
+    if (k == NPIECE - 1) {
+      if (++ch_n == nchunk) { ch_n = 0; ++tap_n; }
+      dma_pending = false;
+    }
+#ifndef US_NO_SCHEDBAR
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+  auto dma_slot = [&](int sidx) {
+    if (US_DMA_SPREAD && F16 && sidx % PSTRIDE == 0 && sidx / PSTRIDE < NPIECE) dma_piece(sidx / PSTRIDE);
+  };
   auto dma_late = [&]() {
     if (NSTG == 3 && dma_pending) {
 #ifndef US_NO_SCHEDBAR
@@ -374,7 +430,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #endif
     }
   };
-  auto mma = [&](const f32x4* fa, const f32x4* fb) {
+  auto mma = [&](const f32x4* fa, const f32x4* fb, int phase = 0) {      // phase: first / second 16-deep step of the chunk (F16)
     if (F16) {
 #pragma unroll
       for (int i = 0; i < MB; ++i)
@@ -382,10 +438,14 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
           const half8 ah = __builtin_bit_cast(half8, fa[i * 2]), al = __builtin_bit_cast(half8, fa[i * 2 + 1]);
           const half8 bh = __builtin_bit_cast(half8, fb[j * 2]), bl = __builtin_bit_cast(half8, fb[j * 2 + 1]);
+          const int s0 = phase * (SLOTS / 2) + (i * 2 + j) * 3;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+          dma_slot(s0);
           total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, total[i][j], 0, 0, 0);
+          dma_slot(s0 + 1);
           total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, total[i][j], 0, 0, 0);
-          if (i == 0 && j == 0) dma_late();
+          dma_slot(s0 + 2);
+          if (!US_DMA_SPREAD && i == 0 && j == 0) dma_late();
         }
       return;
     }
@@ -422,14 +482,32 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     // (everybody's pieces have landed, and everybody is done reading chunk s-1, whose buffer chunk s+2 is about to overwrite),
     // issue chunk s+2, multiply chunk s.
     int cur = 0;
+#ifdef US_STAMP      // diagnostic build (tools/conv_bench): where does a step of the three-buffer loop spend its cycles?
+    unsigned long long st_wait = 0, st_bar = 0, st_body = 0, st_t0, st_t1, st_t2;
+#define US_STAMP_AT(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+    US_STAMP_AT(st_t0);
+#endif
     for (int step = 0; step < S_run; ++step) {
       if (step + 1 < S_run) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + IB) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef US_STAMP
+      US_STAMP_AT(st_t1);
+      st_wait += st_t1 - st_t0;
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef US_STAMP
+      US_STAMP_AT(st_t2);
+      st_bar += st_t2 - st_t1;
+#endif
+#ifdef US_ABL_DMA       // timing experiment: no loads in the loop (stale tiles; results are wrong)
+      if (false) {
+#else
       if (step + 2 < S_run) {
+#endif
         dma_pending = true;
         dma_buf = cur == 0 ? 2 : cur - 1;
-        if (!F16 || (a.debug & 64)) dma_late();      // debug bit 64 (tools/conv_bench A/B): issue right after the barrier
+        // fp32 MFMA form, and the first step of the deferred loop (whose first MFMA block does not run): all pieces at once
+        if (!F16 || (a.debug & 64) || (US_DMA_SPREAD && step == 0 && !WINO)) dma_late();
       }
       const float* base = smem + cur * BUF;
       // as in the two-buffer loop, the MFMAs of a chunk's last 16-deep step run after the next barrier, under the first
@@ -438,21 +516,21 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
         // fused output transform: the four Y accumulators leave no room for a second fragment set (256 VGPRs at two waves per
         // SIMD), so the two 16-deep steps of a chunk run one after the other; the co-resident workgroups cover the read latency
         load_frags(fa0, fb0, base, 0);
-        mma(fa0, fb0);
+        mma(fa0, fb0, 0);
         load_frags(fa0, fb0, base, 1);
-        mma(fa0, fb0);
+        mma(fa0, fb0, 1);
         if ((step + 1) % nchunk == 0) fold(step / nchunk);
         cur = cur == 2 ? 0 : cur + 1;
         continue;
       }
       load_frags(fa0, fb0, base, 0);
       if (step > 0) {
-        mma(fa1, fb1);
+        mma(fa1, fb1, 0);
         step_done();
         if (WINO && step % nchunk == 0) fold(step / nchunk - 1);     // ... which completed a frequency
       }
       load_frags(fa1, fb1, base, 1);
-      mma(fa0, fb0);
+      mma(fa0, fb0, 1);
       if (NS == 4) {
         load_frags(fa0, fb0, base, 2);
         mma(fa1, fb1);
@@ -460,7 +538,17 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
         mma(fa0, fb0);
       }
       cur = cur == 2 ? 0 : cur + 1;
+#ifdef US_STAMP
+      US_STAMP_AT(st_t0);
+      st_body += st_t0 - st_t2;
+#endif
     }
+#ifdef US_STAMP
+    if (a.stamp_out && lane == 0) {
+      unsigned long long* o = a.stamp_out + ((blockIdx.x + gridDim.x * blockIdx.z) * NW + wave) * 4;
+      o[0] = st_wait; o[1] = st_bar; o[2] = st_body; o[3] = (unsigned long long)S_run;
+    }
+#endif
     if (!(WINO && F16)) {
       mma(fa1, fb1);
       step_done();
@@ -469,7 +557,13 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   } else {
   for (int step = 0; step < S_run; ++step) {
     const bool has_next = step + 1 < S_run;
-    if (has_next) {
+#ifndef US_DMA_SPREAD2
+#define US_DMA_SPREAD2 0       // two-buffer loop: spreading measured within noise either way (three workgroups per CU already interleave)
+#endif
+    if (has_next && US_DMA_SPREAD2 && F16 && step > 0) {
+      dma_pending = true;          // the pieces go out between this step's MFMAs (dma_slot)
+      dma_buf = (step + 1) & 1;
+    } else if (has_next) {
       if (ch_n == 0) {
         if (WINO) setup_freq(tap_n);
         else setup_tap(tap_n);
@@ -505,12 +599,12 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #else
     load_frags(fa0, fb0, base, 0);
     if (step > 0) {           // last sub-step of the previous chunk (fragments were read before the barrier)
-      mma(fa1, fb1);
+      mma(fa1, fb1, 0);
       step_done();
       if (WINO && step % nchunk == 0) fold(step / nchunk - 1);     // ... which completed a frequency
     }
     load_frags(fa1, fb1, base, 1);
-    mma(fa0, fb0);
+    mma(fa0, fb0, 1);
     if (NS == 4) {
       load_frags(fa0, fb0, base, 2);
       mma(fa1, fb1);

@@ -104,6 +104,7 @@ struct us_decoder {
   bool f16x3_direct = true;  // US_F16X3_DIRECT=0: direct convolutions (1x1, stride 2, transposed, non-Winograd 3x3) stay on fp32 MFMA
   long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
+  bool xcd_z = true;         // US_XCD_Z=0: the Winograd-domain GEMMs dealt to the XCDs by tile only, not by whole frequencies (A/B)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
                             // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
@@ -508,6 +509,7 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
   // GEMM runs over all Bp * th * tw rows at once (no partial tile per item: a level-3 item has only 320 rows)
   a.out = b.wino_m; a.out_ld = N;
   a.B = 16; a.Hin = a.Hs = a.Hout = e.Bp * th; a.Wout = tw; a.ostep = 1;
+  a.xcd_z = e.h->xcd_z;
   err = run_conv(e, a);
   if (err != hipSuccess) return err;
   WinoOutExtra x{};
@@ -900,6 +902,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (const char* wf = getenv("US_F16X3_MIN_LEVEL")) h->f16x3_min_level = atoi(wf);
   if (const char* wf = getenv("US_F16X3_DIRECT")) h->f16x3_direct = atoi(wf) != 0;
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
+  if (const char* wf = getenv("US_XCD_Z")) h->xcd_z = atoi(wf) != 0;
   h->build();
   {
     int max_cin = 2 * h->C.back();

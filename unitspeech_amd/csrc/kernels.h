@@ -50,6 +50,7 @@ struct ConvArgs {
   float* out;            // [B][Hout][Wout][out_ld]
   double* stats;         // optional GroupNorm partial sums [B][8][2][kStatSlots] (sum, sumsq) of acc + bias
   long long wt_bstride;  // per-item weight stride in floats (0 = shared weights)
+  int xcd_z;             // blockIdx.z enumerates independent GEMMs (Winograd frequencies): deal whole z-slices to an XCD (conv_igemm.hip)
   int wt_bdiv;           // item b reads the weights at wt + (b / max(wt_bdiv,1)) * wt_bstride (Winograd: one matrix per frequency)
   int in_ld, out_ld, add_ld;
   int B, Hin, Win, Cin, Hout, Wout, Cout;
@@ -69,6 +70,9 @@ struct ConvArgs {
                          // utterance's result never depends on what it is batched with (sampling)
   float* splitk_ws;      // optional scratch for split-K partial slabs (splitk_ws_floats floats); null disables split-K
   long long splitk_ws_floats;
+#ifdef US_STAMP
+  unsigned long long* stamp_out;   // diagnostic build only: per (workgroup, wave) {cycles at the vmcnt wait, at the barrier, in the body, steps}
+#endif
   int debug;             // timing ablations for tools/conv_bench (0 in production): 1 = no DMA after the prologue,
                          // 2 = no fragment reads after the first, 4 = no barriers
   unsigned long long dy_bits, dx_bits, wtap_bits;   // 4 bits per tap: dy+8, dx+8, weight tap index
