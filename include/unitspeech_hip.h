@@ -162,6 +162,47 @@ int us_tts_durations(const float* logw, const float* x_mask, float* w_ceil, int6
 int us_tts_align(const float* cond_x, const float* w_ceil, const float* x_mask, const int64_t* y_lengths, float* cond_y,
                  float* attn, float* y_mask, int B, int F, int L, int Tp, us_stream stream);
 
+/* ---- the two learned modules of the conditioning producer, inference -------------------------------
+ * `Encoder` (unitspeech/encoder.py:253-308; text encoder and unit encoder are two instances) and `DurationPredictor`
+ * (unitspeech/duration_predictor.py:24-63, reverse=True).  Same conventions as the decoder handle, except that the
+ * activation scratch belongs to the handle (grown on demand with hipMalloc, so these calls cannot be stream-captured
+ * before their first eager run at the same size).  Dropout is the identity (eval mode); `n_contentvec > 0`
+ * (encoder.py:281: a Linear instead of the Embedding) and `heads_share=False` are not built -- no configuration of the
+ * reference uses them (conf/hydra_config.py:85-116). */
+typedef struct us_frontend* us_frontend_handle;
+typedef struct us_encoder_config {
+  int32_t n_vocab;          /* len(symbols) + 1 (text) / n_units (unit encoder) */
+  int32_t n_feats;          /* 80 */
+  int32_t n_channels;       /* 192 */
+  int32_t filter_channels;  /* 768 */
+  int32_t n_heads;          /* 2 */
+  int32_t n_layers;         /* 6 */
+  int32_t kernel_size;      /* 3 (FFN convolutions; the prenet's 3 layers of kernel 5 are fixed, encoder.py:283) */
+  int32_t window_size;      /* 4; 0 = no relative-position terms (window_size=None) */
+} us_encoder_config;
+typedef struct us_duration_config {
+  int32_t in_channels;      /* 192 */
+  int32_t filter_channels;  /* 256 */
+  int32_t kernel_size;      /* 3 */
+  int32_t spk_emb_dim;      /* 256; 0 = no speaker conditioning (g = None) */
+} us_duration_config;
+int us_encoder_create(us_frontend_handle* out, const us_encoder_config* cfg);
+int us_duration_predictor_create(us_frontend_handle* out, const us_duration_config* cfg);
+int us_frontend_destroy(us_frontend_handle h);
+/* `load_state_dict` for one tensor, reference key and layout (Conv1d [out,in,k], Embedding [vocab,channels], emb_rel_* [1,2W+1,D]). */
+int us_frontend_load_weight(us_frontend_handle h, const char* key, const float* data, const int64_t* shape, int ndim, us_stream stream);
+int us_frontend_num_weights(us_frontend_handle h);
+const char* us_frontend_weight_key(us_frontend_handle h, int i);
+const char* us_frontend_last_error(us_frontend_handle h);
+/* `Encoder.forward(x, x_lengths)` (:294-308): ids [B,L] int64, lengths [B] int64 (device) ->
+ * mu_x [B,n_feats,L], x [B,n_channels,L], x_mask [B,1,L]. */
+int us_encoder_forward(us_frontend_handle h, const int64_t* ids, const int64_t* lengths, float* mu_x, float* x, float* x_mask, int B, int L,
+                       us_stream stream);
+/* `DurationPredictor.forward(x, x_mask, w=None, g=g, reverse=True)` (:47-63): x [B,in_channels,L], x_mask [B,1,L],
+ * g [B,1,spk_emb_dim] (NULL iff spk_emb_dim == 0) -> logw [B,1,L]. */
+int us_duration_predictor_forward(us_frontend_handle h, const float* x, const float* x_mask, const float* g, float* logw, int B, int L,
+                                  us_stream stream);
+
 /* ---- one building block of the score network on its own (parity tests against per-module reference outputs) ---------
  * prefix: the module's state_dict prefix ("estimator.downs.1.1", "estimator.downs.1.2", "estimator.downs.1.3",
  * "estimator.ups.1.3"); level: resolution level whose geometry (n_feats >> level) x (T >> level) the block runs at.

@@ -4,8 +4,8 @@ decoder swapped for `unitspeech_amd.UnitSpeech`.
 
 Two modes:
   default       the reference's call sequence (inference.py:34-160): phonemiser, text encoder, duration predictor, BigVGAN
-                and the checkpoints come from a checkout of the reference given with --reference_root (they stay on the
-                stock PyTorch path; only `decoder.execute_text_to_speech` runs on the HIP library).
+                and the checkpoints come from a checkout of the reference given with --reference_root (phonemiser and vocoder
+                stay on the stock PyTorch path; text encoder, duration predictor, alignment and decoder run on the HIP library).
   --synthetic   no checkpoints / espeak / vocoder are needed: seeded synthetic decoder weights, a deterministic stand-in for
                 the text encoder + duration predictor (same call signatures), output = de-normalised mel saved as .npy.
                 This is the plumbing check of BASELINE.json configs[0] (10 diffusion steps, short text).
@@ -22,6 +22,8 @@ import torch
 
 from unitspeech_amd import DecoderConfig, UnitSpeech, synthetic_state_dict
 from unitspeech_amd.checkpoint import build_decoder, load_decoder_checkpoint
+from unitspeech_amd.encoder import (DurationPredictor, DurationPredictorConfig, Encoder, EncoderConfig, synthetic_duration_predictor_state_dict,
+                                    synthetic_encoder_state_dict)
 from unitspeech_amd.frontend import SyntheticFrontEnd, text_to_ids
 
 
@@ -35,6 +37,8 @@ def main():
     ap.add_argument("--length_scale", type=float, default=1.0)
     ap.add_argument("--diffusion_steps", type=int, default=50)
     ap.add_argument("--synthetic", action="store_true", help="synthetic weights and front-end stand-ins (no checkpoints needed)")
+    ap.add_argument("--learned_frontend", action="store_true",
+                    help="--synthetic: run the HIP text encoder + duration predictor with seeded weights instead of the closed-form stand-ins")
     ap.add_argument("--reference_root", type=str, default=None, help="checkout of adrianstanea/UnitSpeech (non-synthetic mode)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -50,8 +54,18 @@ def main():
         decoder = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
         decoder.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, 0).items()})
         decoder = decoder.to(device).eval()
-        fe = SyntheticFrontEnd(cfg.n_feats, device)
-        text_encoder, duration_predictor = fe.text_encoder, fe.duration_predictor
+        if args.learned_frontend:
+            # the HIP text encoder + duration predictor at the reference's sizes (conf/hydra_config.py:85-116) with seeded weights
+            ec, dc = EncoderConfig(n_vocab=256), DurationPredictorConfig()
+            text_encoder = Encoder(ec.n_vocab, ec.n_feats, ec.n_channels, ec.filter_channels, ec.n_heads, ec.n_layers, ec.kernel_size, 0.1,
+                                   window_size=ec.window_size)
+            text_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_encoder_state_dict(ec, 0).items()})
+            duration_predictor = DurationPredictor(dc.in_channels, dc.filter_channels, dc.kernel_size, 0.1, spk_emb_dim=dc.spk_emb_dim)
+            duration_predictor.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_duration_predictor_state_dict(dc, 0).items()})
+            text_encoder, duration_predictor = text_encoder.to(device).eval(), duration_predictor.to(device).eval()
+        else:
+            fe = SyntheticFrontEnd(cfg.n_feats, device)
+            text_encoder, duration_predictor = fe.text_encoder, fe.duration_predictor
         spk = np.random.Generator(np.random.Philox(key=args.ID & 0xffff)).standard_normal((1, 1, cfg.spk_emb_dim), dtype=np.float32)
         spk_emb = torch.from_numpy(spk / np.linalg.norm(spk)).to(device)
         mel_min, mel_max = torch.tensor(-11.5, device=device), torch.tensor(2.0, device=device)
@@ -62,8 +76,6 @@ def main():
             raise SystemExit("give --reference_root (reference checkout with its checkpoints) or use --synthetic")
         sys.path.insert(0, args.reference_root)
         from conf.hydra_config import MainConfig as rcfg                                   # noqa: E402
-        from unitspeech.duration_predictor import DurationPredictor                         # noqa: E402
-        from unitspeech.encoder import Encoder                                               # noqa: E402
         from unitspeech.text import cleaned_text_to_sequence, phonemize, symbols           # noqa: E402
         from unitspeech.util import get_phonemizer, get_vocoder, intersperse                # noqa: E402
         root = args.reference_root
@@ -73,11 +85,13 @@ def main():
         dd = load_decoder_checkpoint(ck)                                                   # inference.py:66-74,107-108,124
         decoder = build_decoder(dd, device).eval()
         mel_max, mel_min, spk_emb = dd.mel_max.to(device), dd.mel_min.to(device), dd.speaker_embedding(max(args.ID, 0)).to(device)
-        e = rcfg.encoder
+        # text encoder and duration predictor: the HIP modules (same constructor arguments and state_dict keys as the reference's
+        # classes, inference.py:77-105), loaded from the reference's own checkpoints
+        e = rcfg.text_encoder
         text_encoder = Encoder(n_vocab=len(symbols) + 1, n_feats=cfg.n_feats, n_channels=e.n_channels, filter_channels=e.filter_channels,
                                n_heads=e.n_heads, n_layers=e.n_layers, kernel_size=e.kernel_size, p_dropout=e.p_dropout,
                                window_size=e.window_size).to(device)
-        text_encoder.load_state_dict(torch.load(os.path.join(root, rcfg.text_encoder.checkpoint), map_location="cpu")["model"])
+        text_encoder.load_state_dict(torch.load(os.path.join(root, e.checkpoint), map_location="cpu")["model"])
         d = rcfg.duration_predictor
         duration_predictor = DurationPredictor(in_channels=d.in_channels, filter_channels=d.filter_channels, kernel_size=d.kernel_size,
                                                p_dropout=d.p_dropout, spk_emb_dim=d.spk_emb_dim).to(device)

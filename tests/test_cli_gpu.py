@@ -19,6 +19,15 @@ def test_inference_cli_synthetic(tmp_path):
     assert mel.shape[0] == 80 and mel.shape[1] > 0 and np.isfinite(mel).all()
 
 
+def test_inference_cli_with_the_hip_text_encoder_and_duration_predictor(tmp_path):
+    out = tmp_path / "sample.wav"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "inference.py"), "--synthetic", "--learned_frontend", "--text", "buna ziua",
+                        "--diffusion_steps", "3", "--generated_sample_path", str(out)], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mel = np.load(str(out)[:-4] + ".mel.npy")
+    assert mel.shape[0] == 80 and mel.shape[1] >= 19 and np.isfinite(mel).all()        # 19 symbols, at least one frame each
+
+
 def test_finetune_cli_synthetic(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "finetune.py"), "--synthetic", "--n_iters", "3", "--ID", "5", "--out_dir", str(tmp_path)],
                        capture_output=True, text=True, timeout=300, cwd=ROOT)

@@ -19,6 +19,15 @@ class us_config(C.Structure):
                 ("spk_emb_dim", C.c_int32), ("beta_min", C.c_float), ("beta_max", C.c_float), ("pe_scale", C.c_float)]
 
 
+class us_encoder_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_vocab", "n_feats", "n_channels", "filter_channels", "n_heads", "n_layers", "kernel_size",
+                                         "window_size")]
+
+
+class us_duration_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_channels", "filter_channels", "kernel_size", "spk_emb_dim")]
+
+
 # symbol -> (restype, argtypes); must list every function declared in include/unitspeech_hip.h
 SIGNATURES = {
     "us_decoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(us_config)]),
@@ -51,6 +60,15 @@ SIGNATURES = {
     "us_finetune_segment": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p]),
     "us_tts_durations": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "us_tts_align": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
+    "us_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(us_encoder_config)]),
+    "us_duration_predictor_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(us_duration_config)]),
+    "us_frontend_destroy": (C.c_int, [C.c_void_p]),
+    "us_frontend_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    "us_frontend_num_weights": (C.c_int, [C.c_void_p]),
+    "us_frontend_weight_key": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "us_frontend_last_error": (C.c_char_p, [C.c_void_p]),
+    "us_encoder_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    "us_duration_predictor_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p]),
     "us_debug_block": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "us_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
