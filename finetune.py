@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--torch_optimizer", action="store_true", help="clip_grad_norm_ + torch.optim.Adam instead of the HIP clip+Adam")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel of an iteration eagerly instead of replaying one captured HIP graph")
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--learned_frontend", action="store_true", help="--synthetic: cond_x from the HIP unit encoder (seeded weights) on synthetic units")
     ap.add_argument("--reference_root", type=str, default=None)
     ap.add_argument("--out_dir", type=str, default="checkpoints/inference")
     ap.add_argument("--decoder_checkpoint", type=str, default=None,
@@ -64,6 +65,16 @@ def main():
         Lu = L // 3
         mel = torch.from_numpy(g.standard_normal((1, cfg.n_feats, L), dtype=np.float32)).clamp(-1, 1).to(device)
         cond_x = (torch.from_numpy(g.standard_normal((1, cfg.n_feats, Lu), dtype=np.float32)) * 0.5).to(device)
+        if args.learned_frontend:
+            # finetune.py:66-78,122-123: cond_x is the (frozen, eval-mode) unit encoder's output for the utterance's unit sequence;
+            # here the HIP Encoder at the reference's sizes (n_vocab = n_units = 1000) with seeded weights on synthetic units
+            from unitspeech_amd.encoder import Encoder, EncoderConfig, synthetic_encoder_state_dict
+            ec = EncoderConfig(n_vocab=1000, n_feats=cfg.n_feats)
+            unit_encoder = Encoder(ec.n_vocab, ec.n_feats, ec.n_channels, ec.filter_channels, ec.n_heads, ec.n_layers, ec.kernel_size, 0.1,
+                                   window_size=ec.window_size)
+            unit_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_encoder_state_dict(ec, 0).items()})
+            unit = torch.from_numpy(g.integers(0, ec.n_vocab, size=(1, Lu)).astype(np.int64)).to(device)
+            cond_x, _, _ = unit_encoder.to(device).eval()(unit, torch.LongTensor([Lu]).to(device))
         duration = torch.full((1, Lu), 3.0, device=device)
         spk = torch.from_numpy(g.standard_normal((1, 1, cfg.spk_emb_dim), dtype=np.float32)).to(device)
         spk_emb = spk / spk.norm()

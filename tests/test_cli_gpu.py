@@ -29,7 +29,8 @@ def test_inference_cli_with_the_hip_text_encoder_and_duration_predictor(tmp_path
 
 
 def test_finetune_cli_synthetic(tmp_path):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "finetune.py"), "--synthetic", "--n_iters", "3", "--ID", "5", "--out_dir", str(tmp_path)],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "finetune.py"), "--synthetic", "--learned_frontend", "--n_iters", "3", "--ID", "5",
+                        "--out_dir", str(tmp_path)],
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     import torch
