@@ -51,15 +51,19 @@ struct Conv1dArgs {
   int L, Cin, Cout, K;
   int mask_in, relu, mask_out;
 };
-constexpr int kConvTT = 8;       // symbols per workgroup
+constexpr int kConvTT = 4;       // symbols per workgroup
+constexpr int kConvCo = 64;      // output channels per workgroup (one per lane)
+constexpr int kConvKg = 8;       // the (tap, ci) range is cut into 8 contiguous parts, one per wave
 
-// torch.nn.Conv1d(padding = K/2) on channel-last rows: one thread per output channel, kConvTT symbols per workgroup whose
-// (kConvTT + K - 1) x Cin input rows sit in LDS; the weight row [tap][ci][:] is read coalesced and reused for the kConvTT
-// symbols.  fp32 FMA chain in (tap, ci) order starting from the bias.
-__global__ void __launch_bounds__(256) fe_conv1d_kernel(Conv1dArgs a) {
-  extern __shared__ float xs[];                     // [(kConvTT + K - 1)][Cin]
+// torch.nn.Conv1d(padding = K/2) on channel-last rows.  A workgroup owns kConvTT symbols x 64 output channels; its
+// (kConvTT + K - 1) x Cin input rows sit in LDS.  Lane = output channel (the weight row [tap][ci][:] is read coalesced and reused
+// for the kConvTT symbols), wave = eighth of the (tap, ci) range; the eight partial sums meet in LDS and are added in a fixed
+// order ((bias + p0) + p1 + ... + p7), each an fp32 FMA chain in (tap, ci) order: deterministic, batch-independent.
+__global__ void __launch_bounds__(64 * kConvKg) fe_conv1d_kernel(Conv1dArgs a) {
+  extern __shared__ float xs[];                     // [(kConvTT + K - 1)][Cin], then [kConvKg][kConvTT][64] partial sums
   const int b = blockIdx.y, t0 = blockIdx.x * kConvTT, pad = a.K / 2;
   const int rows = kConvTT + a.K - 1;
+  float* part = xs + rows * a.Cin;
   for (int i = threadIdx.x; i < rows * a.Cin; i += blockDim.x) {
     const int r = i / a.Cin, ci = i - r * a.Cin, t = t0 + r - pad;
     float v = 0.f;
@@ -70,26 +74,40 @@ __global__ void __launch_bounds__(256) fe_conv1d_kernel(Conv1dArgs a) {
     xs[i] = v;
   }
   __syncthreads();
-  for (int co = blockIdx.z * blockDim.x + threadIdx.x; co < a.Cout; co += gridDim.z * blockDim.x) {
-    float acc[kConvTT];
-    const float bv = a.bias[co];
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int co = blockIdx.z * kConvCo + lane;
+  const int n_red = a.K * a.Cin;                                   // flattened (tap, ci)
+  const int lo = (int)(((long long)n_red * kg) / kConvKg), hi = (int)(((long long)n_red * (kg + 1)) / kConvKg);
+  float acc[kConvTT];
 #pragma unroll
-    for (int tt = 0; tt < kConvTT; ++tt) acc[tt] = bv;
-    for (int k = 0; k < a.K; ++k) {
-      const float* wk = a.w + (long long)k * a.Cin * a.Cout + co;
-      const float* xk = xs + k * a.Cin;
-      for (int ci = 0; ci < a.Cin; ++ci) {
-        const float wv = wk[(long long)ci * a.Cout];
+  for (int tt = 0; tt < kConvTT; ++tt) acc[tt] = 0.f;
+  if (co < a.Cout) {
+    if (kg == 0) {
+      const float bv = a.bias[co];
 #pragma unroll
-        for (int tt = 0; tt < kConvTT; ++tt) acc[tt] = __builtin_fmaf(xk[tt * a.Cin + ci], wv, acc[tt]);
-      }
+      for (int tt = 0; tt < kConvTT; ++tt) acc[tt] = bv;
     }
+    // input row of (symbol tt, tap k) is tt + k, so element (tt, k, ci) sits at xs[tt * Cin + r] with r = k * Cin + ci
+    const float* wp = a.w + co;
+#pragma unroll 8
+    for (int r = lo; r < hi; ++r) {
+      const float wv = wp[(long long)r * a.Cout];
+#pragma unroll
+      for (int tt = 0; tt < kConvTT; ++tt) acc[tt] = __builtin_fmaf(xs[tt * a.Cin + r], wv, acc[tt]);
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < kConvTT; ++tt) part[(kg * kConvTT + tt) * kConvCo + lane] = acc[tt];
+  __syncthreads();
+  if (kg == 0 && co < a.Cout) {
 #pragma unroll
     for (int tt = 0; tt < kConvTT; ++tt) {
       const int t = t0 + tt;
       if (t >= a.L) break;
-      const long long o = ((long long)b * a.L + t) * a.Cout + co;
       float v = acc[tt];
+#pragma unroll
+      for (int g = 1; g < kConvKg; ++g) v = add_rn(v, part[(g * kConvTT + tt) * kConvCo + lane]);
+      const long long o = ((long long)b * a.L + t) * a.Cout + co;
       if (a.relu) v = v > 0.f ? v : 0.f;
       if (a.add) v = add_rn(a.add[o], v);
       if (a.mask_out) v *= a.mask[(long long)b * a.L + t];
@@ -376,10 +394,9 @@ int conv1d(us_frontend* h, hipStream_t s, const std::string& prefix, const float
   a.in = in; a.w = w.packed; a.bias = h->w[prefix + ".bias"].dev; a.mask = mask; a.add = add; a.out = out;
   a.L = L; a.Cout = (int)w.shape[0]; a.Cin = (int)w.shape[1]; a.K = (int)w.shape[2];
   a.mask_in = mask_in; a.relu = relu; a.mask_out = mask_out;
-  const size_t lds = (size_t)(kConvTT + a.K - 1) * a.Cin * sizeof(float);
-  if (lds > 64 * 1024) return fe_fail(h, US_EINVAL, "front-end conv1d: (8 + K - 1) * Cin rows do not fit 64 KB of LDS");
-  const int threads = a.Cout >= 256 ? 256 : ((a.Cout + 63) / 64) * 64;
-  hipLaunchKernelGGL(fe_conv1d_kernel, dim3((L + kConvTT - 1) / kConvTT, B, (a.Cout + threads - 1) / threads), dim3(threads), lds, s, a);
+  const size_t lds = ((size_t)(kConvTT + a.K - 1) * a.Cin + (size_t)kConvKg * kConvTT * kConvCo) * sizeof(float);
+  if (lds > 64 * 1024) return fe_fail(h, US_EINVAL, "front-end conv1d: (4 + K - 1) * Cin rows do not fit 64 KB of LDS");
+  hipLaunchKernelGGL(fe_conv1d_kernel, dim3((L + kConvTT - 1) / kConvTT, B, (a.Cout + kConvCo - 1) / kConvCo), dim3(64 * kConvKg), lds, s, a);
   return US_OK;
 }
 
