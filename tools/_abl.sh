@@ -1,6 +1,4 @@
 set -e
-hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/cb
-for r in 1 2; do
-echo "== in-kernel split"; CB_ONLY="1x1" CB_F16=1 /tmp/cb 9 | grep TFLOP
-echo "== pre-split A"; CB_ONLY="1x1" CB_F16=1 CB_PRESPLIT=1 /tmp/cb 9 | grep TFLOP
-done
+python -m pytest tests -m gpu -x -q -k "grad or loss or fine_tune or finetune or backward" 2>&1 | tail -2
+for r in 1 2; do for v in 0 1; do echo "== US_WGRAD_F16=$v"; US_WGRAD_F16=$v python bench_finetune.py --no-cpu-baseline --iters 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('finetune ms', d['value']*1e3)"; done; done
+for v in 0 1; do echo "== pretrain US_WGRAD_F16=$v"; US_WGRAD_F16=$v python bench_pretrain.py 2>/dev/null | tail -1 | cut -c1-260; done

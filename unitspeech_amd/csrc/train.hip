@@ -206,6 +206,170 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
       }
 }
 
+// f16x3 form of the LDS-staged kernel (same grid, tile and arguments): the reduction runs over PIXELS, so the fp16 MFMA's eight
+// consecutive k values of a lane are eight pixels of one channel -- a transpose of the pixel-major activations.  A stage of 16
+// pixels x 128 channels per operand is DMA'd to LDS as it lies in memory (fp32, [pixel][channel]); the workgroup then converts it
+// ONCE into the fragment image (per channel 64 bytes: hi plane of the 16 pixels, lo plane; 16-byte chunks XOR-swizzled by
+// (channel >> 2) & 3 so that both the converting writes and the fragment reads spread over the banks) and every wave reads its
+// fragments from there with ds_read_b128: each value is split once per workgroup, not once per wave that uses it.
+// Gradients are small (a mean-reduced loss puts dL/dy around 1e-5, below fp16's normal range), so the workgroup first takes the
+// absolute maximum of ITS slice of gy and multiplies by the power of two that brings it to [2^14, 2^15): exact, undone on the
+// accumulators at the end.  hi = fp16(v), lo = fp16((v - hi) * 2^11); C = C_hh + 2^-11 C_x as in conv_igemm.hip.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+constexpr int kWgKP16 = 16;
+
+__global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];      // raw: 2 stages x (A [16][128] + B [16][128]) fp32; then the fragment image
+  constexpr int RAW = 2 * kWgKP16 * 128;                           // floats per raw stage (both operands)
+  float* cimg = wsm + 2 * RAW;                                     // [2 operands][128 channels][16 floats = 64 bytes]
+  __shared__ float s_red[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, hh = lane >> 5;
+  const int Ms = a.Hs * a.Ws;
+  const int chunks_per_item = (Ms + a.chunk - 1) / a.chunk;
+  const int b = blockIdx.x / chunks_per_item;
+  const int m_lo = (blockIdx.x % chunks_per_item) * a.chunk;
+  int m_hi = m_lo + a.chunk;
+  if (m_hi > Ms) m_hi = Ms;
+  const int nci = a.Cin / 128;
+  const int co0 = (blockIdx.y / nci) * 128, ci0 = (blockIdx.y % nci) * 128;
+  const int tap = blockIdx.z;
+  const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
+  const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
+  const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);
+  const unsigned gy_bytes = (unsigned)a.Hout * (unsigned)a.Wout * (unsigned)a.gy_ld * 4u;
+  const unsigned x_bytes = (unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.x_ld * 4u;
+  const float* gy_b = a.gy + (long long)b * a.Hout * a.Wout * a.gy_ld;
+  const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc((void*)gy_b, 0, (int)gy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.Hin * a.Win * a.x_ld), 0, (int)x_bytes, 0x00020000);
+
+  // ---- scale of the gradient operand: absolute maximum over this workgroup's pixels x 128 output channels
+  float mx = 0.f;
+  {
+    const int rl = tid >> 5, ch = (tid & 31) * 4;       // 8 pixel rows per pass, a channel quad per thread
+    for (int m = m_lo + rl; m < m_hi; m += 8) {
+      const int yy = m / a.Ws, xx = m - yy * a.Ws;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(gy_b + ((long long)(a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * a.gy_ld + co0 + ch);
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  }
+  // 2^(14 - floor(log2 mx)), kept inside the normal range; an all-zero (or non-finite) slice is left unscaled
+  int e2 = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
+  int se = 14 - e2;
+  if (!(mx > 0.f) || e2 > 127) se = 0;
+  se = se < -100 ? -100 : (se > 100 ? 100 : se);
+  const float g_scale = __uint_as_float((unsigned)(127 + se) << 23), g_unscale = __uint_as_float((unsigned)(127 - se) << 23);
+
+  // DMA role as in wgrad_lds_kernel: instruction j of this wave covers stage rows wave*4 + 2j + (lane>>5), channels (lane&31)*4..+3
+  const int lrow = lane >> 5, lch = (lane & 31) * 4;
+  auto dma = [&](int stage_m0, int buf) {
+    float* As = wsm + buf * RAW;
+    float* Bs = As + kWgKP16 * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wave * 4 + 2 * j;
+      const int m = stage_m0 + r + lrow;
+      unsigned goff = gy_bytes, xoff = x_bytes;      // out of range: zeros
+      if (m < m_hi) {
+        const int yy = m / a.Ws, xx = m - yy * a.Ws;
+        goff = ((unsigned)((a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * (unsigned)a.gy_ld + (unsigned)(co0 + lch)) * 4u;
+        const int iy = yy * a.istride + dy, ix = xx * a.istride + dx;
+        if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
+          xoff = ((unsigned)(iy * a.Win + ix) * (unsigned)a.x_ld + (unsigned)(ci0 + lch)) * 4u;
+      }
+      wg_blds16(rsrc_g, goff, As + r * 128);
+      wg_blds16(rsrc_x, xoff, Bs + r * 128);
+    }
+  };
+  // conversion role: unit u = (operand, channel, pixel octet); thread t takes (operand 0, channel t & 127, octet t >> 7) and the same
+  // of operand 1.  16-byte chunk j of a channel's 64 bytes (hi octet 0, hi octet 1, lo octet 0, lo octet 1) sits at j ^ ((c >> 2) & 3).
+  const int cv_c = tid & 127, cv_o = tid >> 7;
+  const int cv_sw = (cv_c >> 2) & 3;
+  auto convert = [&](int buf) {
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const float* src = wsm + buf * RAW + op * (kWgKP16 * 128) + (cv_o * 8) * 128 + cv_c;
+      const float sc = op == 0 ? g_scale : 1.f;
+      half8_t hi, lo;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = __builtin_amdgcn_fmed3f(src[k * 128] * sc, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)v;
+        hi[k] = h;
+        lo[k] = (_Float16)((v - (float)h) * 2048.f);
+      }
+      float* row = cimg + (op * 128 + cv_c) * 16;
+      *reinterpret_cast<half8_t*>(row + ((cv_o ^ cv_sw) << 2)) = hi;
+      *reinterpret_cast<half8_t*>(row + (((2 + cv_o) ^ cv_sw) << 2)) = lo;
+    }
+  };
+
+  f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+  const int nstage = (m_hi - m_lo + kWgKP16 - 1) / kWgKP16;
+  // Two raw buffers at three workgroups per CU (48 KB each) measured better than three buffers (two stages in flight) at two
+  // workgroups per CU: pre-training step 79.2 vs 88.3 ms (fp32 MFMA form: 85.4).
+  dma(m_lo, 0);
+  for (int st = 0; st < nstage; ++st) {
+    // this wave's pieces of stage st have landed; after the barrier everybody's have, and everybody has read the image of st-1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < nstage) dma(m_lo + (st + 1) * kWgKP16, (st + 1) & 1);      // its buffer was converted at stage st-1
+    convert(st & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    half8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ca = wm * 64 + i * 32 + l32, cb = wn * 64 + i * 32 + l32;
+      const float* ra = cimg + ca * 16;
+      const float* rb = cimg + (128 + cb) * 16;
+      const int sa = (ca >> 2) & 3, sb = (cb >> 2) & 3;
+      ah[i] = *reinterpret_cast<const half8_t*>(ra + ((hh ^ sa) << 2));
+      al[i] = *reinterpret_cast<const half8_t*>(ra + (((2 + hh) ^ sa) << 2));
+      bh[i] = *reinterpret_cast<const half8_t*>(rb + ((hh ^ sb) << 2));
+      bl[i] = *reinterpret_cast<const half8_t*>(rb + (((2 + hh) ^ sb) << 2));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+      }
+  }
+  float* gw = a.gw + (long long)b * a.gw_bstride + (long long)wt_i * a.Cout * a.Cin;
+  const bool single = chunks_per_item == 1 && (a.B == 1 || a.gw_bstride != 0);    // the only writer of these elements
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int ci = ci0 + wn * 64 + j * 32 + l32;
+        float* dst = gw + (long long)co * a.Cin + ci;
+        const float v = __builtin_fmaf(accx[i][j][r], 0x1p-11f, acc[i][j][r]) * g_unscale;
+        if (single) *dst = a.overwrite ? v : *dst + v;
+        else atomicAdd(dst, v);
+      }
+}
+
 static bool wgrad_use_lds(const WgradArgs& a) {
   static int use_lds = -1;
   if (use_lds < 0) { const char* e = getenv("US_WGRAD_LDS"); use_lds = e ? atoi(e) : 1; }
@@ -232,6 +396,19 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
       attr_set = true;
     }
     dim3 g2(a.B * ((Ms + a.chunk - 1) / a.chunk), (a.Cout / 128) * (a.Cin / 128), a.ntaps);
+    static int use_f16 = -1;       // US_WGRAD_F16=0: the exact-fp32 MFMA form
+    if (use_f16 < 0) { const char* e = getenv("US_WGRAD_F16"); use_f16 = e ? atoi(e) : 1; }
+    if (use_f16) {
+      const int lds16 = (2 * 2 * kWgKP16 * 128 + 2 * 128 * 16) * (int)sizeof(float);
+      static bool attr16_set = false;
+      if (!attr16_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+        if (e != hipSuccess) return e;
+        attr16_set = true;
+      }
+      hipLaunchKernelGGL(wgrad_f16_kernel, g2, dim3(256), lds16, s, a);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL(wgrad_lds_kernel, g2, dim3(256), lds, s, a);
     return hipGetLastError();
   }
