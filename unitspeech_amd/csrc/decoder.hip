@@ -509,7 +509,9 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
   // GEMM runs over all Bp * th * tw rows at once (no partial tile per item: a level-3 item has only 320 rows)
   a.out = b.wino_m; a.out_ld = N;
   a.B = 16; a.Hin = a.Hs = a.Hout = e.Bp * th; a.Wout = tw; a.ostep = 1;
-  a.xcd_z = e.h->xcd_z;
+  // whole frequencies per XCD pay where a frequency's workgroups share operand tiles (nt > 1 column tiles re-reading A, K long enough
+  // for the shared reads to matter): with 128 input or output channels the same placement measured 2-20 % SLOWER
+  a.xcd_z = e.h->xcd_z && K >= 256 && N >= 256;
   err = run_conv(e, a);
   if (err != hipSuccess) return err;
   WinoOutExtra x{};
