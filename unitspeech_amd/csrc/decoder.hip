@@ -103,6 +103,8 @@ struct us_decoder {
   int f16x3_min_level = 0;   // channel counts at levels >= US_F16X3_MIN_LEVEL run as three fp16 MFMA products of split operands
   bool f16x3_direct = true;  // US_F16X3_DIRECT=0: direct convolutions (1x1, stride 2, transposed, non-Winograd 3x3) stay on fp32 MFMA
   long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
+  long long wino_fuse_min_wgs_small = 200;       // US_WINO_FUSE_MIN_WGS_SMALL: ... for matrices of at most
+  long long wino_fuse_small_kn = 512 * 256;      // US_WINO_FUSE_SMALL_KN elements per frequency
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
   bool xcd_z = true;         // US_XCD_Z=0: the Winograd-domain GEMMs dealt to the XCDs by tile only, not by whole frequencies (A/B)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
@@ -485,7 +487,11 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
   // enough workgroups for the chip; otherwise 16x more, shorter workgroups and a separate transform pass.  Both forms add in
   // the same order, so the choice (which depends on the batch) does not change a single bit of the result.
   const long long fused_wgs = (long long)((th * tw + 63) / 64) * ((N + 127) / 128) * e.Bp;
-  if (fused_wgs >= e.h->wino_fuse_min_wgs) {
+  // A fused workgroup streams its column tile's weights for all 16 frequencies (16 * K * 128 values) for only 64 tiles of rows, four
+  // times the weight traffic of the separate form's 256-row tiles: with small matrices (K * N <= 512 * 256) it already pays at about
+  // one workgroup per CU, with the 1024-wide ones only when the launch is several waves deep.
+  const long long min_wgs = (long long)K * N <= e.h->wino_fuse_small_kn ? e.h->wino_fuse_min_wgs_small : e.h->wino_fuse_min_wgs;
+  if (fused_wgs >= min_wgs) {
     a.wino_out = 1;
     a.B = e.Bp; a.Hout = H; a.Wout = W; a.ostep = 2;
     a.out = out; a.out_ld = out_ld;
@@ -900,6 +906,8 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS")) h->wino_fuse_min_wgs = atoll(wf);
+  if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS_SMALL")) h->wino_fuse_min_wgs_small = atoll(wf);
+  if (const char* wf = getenv("US_WINO_FUSE_SMALL_KN")) h->wino_fuse_small_kn = atoll(wf);
   if (const char* wf = getenv("US_F16X3")) h->f16x3 = atoi(wf) != 0;
   if (const char* wf = getenv("US_F16X3_MIN_LEVEL")) h->f16x3_min_level = atoi(wf);
   if (const char* wf = getenv("US_F16X3_DIRECT")) h->f16x3_direct = atoi(wf) != 0;
