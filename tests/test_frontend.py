@@ -69,6 +69,34 @@ def test_state_dict_layout_is_the_reference_modules():
     assert n_params == sum(p.numel() for p in Encoder(150, 80, 192, 768, 2, 6, 3, 0.1, window_size=4).parameters())
 
 
+def test_c_abi_key_tables_match_the_state_dict_layout():
+    """Handle creation does no GPU work: the library's own key list (what `us_frontend_load_weight` accepts, in order) against the
+    layout the goldens' generator asserted equal to the reference modules'; bad configurations are refused with a message."""
+    import ctypes as C
+    from unitspeech_amd import _lib
+    lib = _lib.load()
+    for ecfg, dcfg in CASES.values():
+        h = C.c_void_p()
+        c = _lib.us_encoder_config(ecfg.n_vocab, ecfg.n_feats, ecfg.n_channels, ecfg.filter_channels, ecfg.n_heads, ecfg.n_layers,
+                                   ecfg.kernel_size, ecfg.window_size or 0)
+        assert lib.us_encoder_create(C.byref(h), C.byref(c)) == 0
+        keys = [lib.us_frontend_weight_key(h, i).decode() for i in range(lib.us_frontend_num_weights(h))]
+        assert keys == list(encoder_state_shapes(ecfg)) and lib.us_frontend_weight_key(h, len(keys)) is None
+        assert lib.us_duration_predictor_forward(h, None, None, None, None, 1, 1, None) == -1        # wrong kind of handle: EINVAL
+        assert lib.us_frontend_destroy(h) == 0
+        h = C.c_void_p()
+        c = _lib.us_duration_config(dcfg.in_channels, dcfg.filter_channels, dcfg.kernel_size, dcfg.spk_emb_dim)
+        assert lib.us_duration_predictor_create(C.byref(h), C.byref(c)) == 0
+        keys = [lib.us_frontend_weight_key(h, i).decode() for i in range(lib.us_frontend_num_weights(h))]
+        assert keys == list(duration_predictor_state_shapes(dcfg))
+        assert lib.us_frontend_destroy(h) == 0
+    h = C.c_void_p()
+    bad = _lib.us_encoder_config(150, 80, 192, 768, 5, 6, 3, 4)             # 192 channels over 5 heads
+    assert lib.us_encoder_create(C.byref(h), C.byref(bad)) == -1 and b"bad configuration" in lib.us_frontend_last_error(None)
+    even = _lib.us_duration_config(192, 256, 4, 256)                        # even kernel size
+    assert lib.us_duration_predictor_create(C.byref(h), C.byref(even)) == -1
+
+
 def test_host_side_argument_checks():
     enc = Encoder(20, 8, 16, 32, 2, 2, 3, 0.1, window_size=4).eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
@@ -154,6 +182,28 @@ def test_hip_modules_follow_weight_updates_and_report_errors():
     enc.train()
     with pytest.raises(RuntimeError, match="inference-only"):
         enc(ids, lens)
+
+
+@pytest.mark.gpu
+def test_c_abi_reports_unknown_keys_wrong_shapes_and_missing_weights():
+    import ctypes as C
+    from unitspeech_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    c = _lib.us_duration_config(16, 24, 3, 12)
+    assert lib.us_duration_predictor_create(C.byref(h), C.byref(c)) == 0
+    w = torch.zeros(24, 28, 3, device="cuda")
+    shp = (C.c_int64 * 3)(24, 28, 3)
+    assert lib.us_frontend_load_weight(h, b"conv_9.weight", w.data_ptr(), shp, 3, None) == -2            # ENOKEY
+    bad = (C.c_int64 * 3)(24, 27, 3)
+    assert lib.us_frontend_load_weight(h, b"conv_1.weight", w.data_ptr(), bad, 3, None) == -3            # ESHAPE
+    assert lib.us_frontend_load_weight(h, b"conv_1.weight", w.data_ptr(), shp, 3, None) == 0
+    x, m, g, out = (torch.zeros(n, device="cuda") for n in (16 * 4, 4, 12, 4))
+    assert lib.us_duration_predictor_forward(h, x.data_ptr(), m.data_ptr(), g.data_ptr(), out.data_ptr(), 1, 4, None) == -4      # EWEIGHTS
+    assert b"has not been loaded" in lib.us_frontend_last_error(h)
+    assert lib.us_duration_predictor_forward(h, x.data_ptr(), m.data_ptr(), None, out.data_ptr(), 1, 4, None) == -1               # g missing
+    torch.cuda.synchronize()
+    assert lib.us_frontend_destroy(h) == 0
 
 
 @pytest.mark.gpu
