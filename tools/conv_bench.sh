@@ -1,5 +1,5 @@
 #!/bin/bash
-# builds and runs the conv micro-benchmark on the GPU box: tools/conv_bench.sh [debug masks...]
+# builds and runs the conv micro-benchmark on the GPU box: tools/conv_bench.sh [debug masks...] | f16 [filter] | diag [filter] | prio
 set -e
 cd "$(dirname "$0")/.."
 # production kernel (debug mask 0) and, with -DUS_CONV_ABLATE, the timing-ablation build for masks != 0
@@ -9,6 +9,20 @@ if [ "$1" = f16 ]; then
   /tmp/conv_bench 0 | grep "calibration"
   CB_ONLY="${2:-G}" CB_F16=1 /tmp/conv_bench 9
   CB_ONLY="${2:-G}" /tmp/conv_bench 9
+  exit 0
+fi
+if [ "$1" = diag ]; then
+  # where the three-buffer f16x3 GEMM spends a step: s_memtime stamps, then the timing ablations (results of the
+  # ablated builds are wrong by construction): tools/conv_bench.sh diag [shape filter]
+  B="hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip"
+  $B -DUS_STAMP -o /tmp/cb_stamp & $B -DUS_ABL_LDS -o /tmp/cb_lds & $B -DUS_ABL_DMA -o /tmp/cb_dma & $B -DUS_ABL_DMA -DUS_ABL_LDS -o /tmp/cb_both & $B -DUS_DMA_SPREAD=0 -o /tmp/cb_burst & wait
+  for v in "" _stamp _lds _dma _both _burst; do
+    echo "== build: ${v:-production} (stamp: cycles per step; lds: half the fragment reads; dma: no loads in the loop; burst: LDS-DMA pieces back to back)"
+    if [ -z "$v" ]; then CB_ONLY="${2:-G3 gemm 1024}" CB_F16=1 CB_TM=256 /tmp/conv_bench 9 | grep "TFLOP\|stamps"; else CB_ONLY="${2:-G3 gemm 1024}" CB_F16=1 CB_TM=256 /tmp/cb$v 9 | grep "TFLOP\|stamps"; fi
+  done
+  echo "== whole-frequency XCD placement off / on"
+  CB_NO_XCDZ=1 CB_ONLY="${2:-G}" CB_F16=1 CB_TM=256 /tmp/conv_bench 9 | grep TFLOP
+  CB_ONLY="${2:-G}" CB_F16=1 CB_TM=256 /tmp/conv_bench 9 | grep TFLOP
   exit 0
 fi
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -DUS_CONV_ABLATE tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/conv_bench_ablate
