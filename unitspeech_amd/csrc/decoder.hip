@@ -41,6 +41,7 @@ struct Slot {
   bool direct_f16 = false;  // buf (direct-form pack of a conv that does not run in the Winograd domain) holds the f16x3 form
   bool wino_f16 = false;    // wino holds the f16x3 form (two interleaved fp16 planes per value) instead of fp32
   bool wino_dg_f16 = false; // ... and so does wino_dg
+  bool dg_f16 = false;      // dg holds the f16x3 form (data-gradient GEMM of a direct convolution; K = output channels in 32-chunks)
   int level = -1;        // U-Net level of a ResnetBlock conv
   DevBuf wino_dg;        // ... and of the rotated, channel-swapped filter for the data gradient, [16][Cout/bk_dg][Cin][bk_dg]
   bool want_wino = false;
@@ -101,6 +102,7 @@ struct us_decoder {
   int n_resnets = 0;
   bool f16x3 = true;         // US_F16X3=0: every Winograd GEMM on the fp32 matrix instruction.  Default: those with 32-divisible
   int f16x3_min_level = 0;   // channel counts at levels >= US_F16X3_MIN_LEVEL run as three fp16 MFMA products of split operands
+  bool f16x3_dgrad = true;   // US_F16X3_DGRAD=0: data gradients of the direct convolutions stay on fp32 MFMA
   bool f16x3_direct = true;  // US_F16X3_DIRECT=0: direct convolutions (1x1, stride 2, transposed, non-Winograd 3x3) stay on fp32 MFMA
   long long wino_fuse_min_wgs = 400;   // US_WINO_FUSE_MIN_WGS: fused output transform when the launch keeps this many workgroups
   long long wino_fuse_min_wgs_small = 200;       // US_WINO_FUSE_MIN_WGS_SMALL: ... for matrices of at most
@@ -911,6 +913,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (const char* wf = getenv("US_F16X3")) h->f16x3 = atoi(wf) != 0;
   if (const char* wf = getenv("US_F16X3_MIN_LEVEL")) h->f16x3_min_level = atoi(wf);
   if (const char* wf = getenv("US_F16X3_DIRECT")) h->f16x3_direct = atoi(wf) != 0;
+  if (const char* wf = getenv("US_F16X3_DGRAD")) h->f16x3_dgrad = atoi(wf) != 0;
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
   if (const char* wf = getenv("US_XCD_Z")) h->xcd_z = atoi(wf) != 0;
   h->build();
@@ -938,6 +941,10 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
       s->wino.n = s->wino_dg.n = (size_t)16 * s->shape[0] * s->shape[1];
       ok = hipMalloc(reinterpret_cast<void**>(&s->wino.p), s->wino.n * sizeof(float)) == hipSuccess &&
            hipMalloc(reinterpret_cast<void**>(&s->wino_dg.p), s->wino_dg.n * sizeof(float)) == hipSuccess;
+    }
+    if (ok && s->dg.p && h->f16x3 && h->f16x3_direct && h->f16x3_dgrad) {
+      const long long kk = s->kind == Kind::CONVT_IOHW ? s->shape[1] : s->shape[0];      // the data-gradient GEMM sums over the output channels
+      s->dg_f16 = kk % 32 == 0;
     }
     if (ok && !s->want_wino && s->kind != Kind::RAW && h->f16x3 && h->f16x3_direct) {
       const long long cin = s->kind == Kind::CONV_OIHW ? s->shape[1] : s->shape[0];
@@ -1014,7 +1021,11 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
           if (pc.dst == s->buf.p) { pc.src = data; replaced = true; break; }      // re-loaded before the flush: the later source wins
         if (!replaced) h->pending_copies.push_back(CopyEnt{data, s->buf.p, (long long)s->buf.n});
       }
-      if (s->dg_as_1x1)
+      // data-gradient packs: GEMM-K = output channels, GEMM-N = input channels.  f16x3: the forward pack routine with the channel
+      // roles swapped (an OIHW tensor read as "IOHW" with I = its O)
+      if (s->dg_as_1x1 && s->dg_f16)
+        US_HIP(h, launch_pack_conv_weight_f16(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], 1, 1, false, st));
+      else if (s->dg_as_1x1)
         US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk_dg, st));
       break;
     case Kind::CONV_OIHW:
@@ -1026,12 +1037,14 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
       if (s->wino_dg.p && s->wino_dg_f16) US_HIP(h, launch_wino_pack_weight_f16(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], st, true));
       else if (s->wino_dg.p) US_HIP(h, launch_wino_pack_weight(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], s->bk_dg, st, true));
+      else if (s->dg_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, st));
       else US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
       break;
     case Kind::CONVT_IOHW:
       if (s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, st));
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));
-      US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk_dg, st));
+      if (s->dg_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, st));
+      else US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk_dg, st));
       break;
   }
   s->loaded = true;

@@ -109,6 +109,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // (`buffer_load_dwordx4 ... lds`, one wave instruction = 2 pixel rows x 128 channels, out-of-image taps and rows past the
 // chunk read zeros through the descriptor's range check), double-buffered.  32 FLOP per LDS byte instead of one global load
 // per MFMA operand.
+// Grid order of the LDS-staged weight-gradient kernels.  The taps of one (pixel chunk, channel tile) read the same gy rows and the same
+// x rows shifted by a pixel or a row, so they should run back to back on ONE XCD (workgroups are dealt round-robin over the 8 XCDs in
+// linear order, each XCD with its own L2): with the tap as the slowest grid index every tap re-streamed both tensors from memory
+// (nine times 460 MB per level-0 convolution at 32 crops).  Linear id L -> XCD L % 8, position j = L / 8 on it; consecutive j take the
+// taps of one (chunk, tile), then the next (chunk, tile) of that XCD.
+struct WgIdx { int bx, by, tap; };
+__device__ __forceinline__ WgIdx wgrad_index() {
+  WgIdx r{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  const unsigned nxy = gridDim.x * gridDim.y, nt = gridDim.z;
+  if ((nxy & 7u) == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned rest = (j / nt) * 8u + xcd;      // < nxy because (nxy / 8) * nt positions per XCD
+    r.tap = (int)(j % nt);
+    r.bx = (int)(rest % gridDim.x);
+    r.by = (int)(rest / gridDim.x);
+  }
+  return r;
+}
+
 constexpr int kWgKP = 32;
 __device__ __forceinline__ void wg_blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff_bytes, float* lds_dst_wave_uniform) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, (int)voff_bytes, 0, 0, 0);
@@ -122,13 +142,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
   const int l32 = lane & 31, hh = lane >> 5;
   const int Ms = a.Hs * a.Ws;
   const int chunks_per_item = (Ms + a.chunk - 1) / a.chunk;
-  const int b = blockIdx.x / chunks_per_item;
-  const int m_lo = (blockIdx.x % chunks_per_item) * a.chunk;
+  const WgIdx wi = wgrad_index();
+  const int b = wi.bx / chunks_per_item;
+  const int m_lo = (wi.bx % chunks_per_item) * a.chunk;
   int m_hi = m_lo + a.chunk;
   if (m_hi > Ms) m_hi = Ms;
   const int nci = a.Cin / 128;
-  const int co0 = (blockIdx.y / nci) * 128, ci0 = (blockIdx.y % nci) * 128;
-  const int tap = blockIdx.z;
+  const int co0 = (wi.by / nci) * 128, ci0 = (wi.by % nci) * 128;
+  const int tap = wi.tap;
   const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
   const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
   const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);
@@ -229,13 +250,14 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
   const int l32 = lane & 31, hh = lane >> 5;
   const int Ms = a.Hs * a.Ws;
   const int chunks_per_item = (Ms + a.chunk - 1) / a.chunk;
-  const int b = blockIdx.x / chunks_per_item;
-  const int m_lo = (blockIdx.x % chunks_per_item) * a.chunk;
+  const WgIdx wi = wgrad_index();
+  const int b = wi.bx / chunks_per_item;
+  const int m_lo = (wi.bx % chunks_per_item) * a.chunk;
   int m_hi = m_lo + a.chunk;
   if (m_hi > Ms) m_hi = Ms;
   const int nci = a.Cin / 128;
-  const int co0 = (blockIdx.y / nci) * 128, ci0 = (blockIdx.y % nci) * 128;
-  const int tap = blockIdx.z;
+  const int co0 = (wi.by / nci) * 128, ci0 = (wi.by % nci) * 128;
+  const int tap = wi.tap;
   const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
   const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
   const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);

@@ -115,6 +115,15 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _grad_scale(n_elements: int) -> float:
+    """Power of two applied to the gradient entering `us_estimator_backward` (and removed from its results): 1 up to 2^14 elements in
+    the loss's mean (one 176-frame crop), doubling with every doubling beyond.  UNITSPEECH_GRAD_SCALE_LOG2 overrides the exponent."""
+    import os
+    e = os.environ.get("UNITSPEECH_GRAD_SCALE_LOG2")
+    k = int(e) if e is not None else max(0, int(math.floor(math.log2(max(n_elements, 1)))) - 13)
+    return float(2 ** min(k, 24))
+
+
 class _Engine:
     """Owns one `us_handle`, its weight synchronisation state and the scratch workspace."""
 
@@ -130,9 +139,18 @@ class _Engine:
         self.handle = C.c_void_p()
         self.device = None
         self.last_grad_blob = None
+        self._scalars = {}
         self.versions = {}
         self._key_meta = {}         # key -> (bytes key, ctypes shape array, shape)
         self.workspace = None
+
+    def scalar(self, value: float, device) -> torch.Tensor:
+        """Device-resident fp32 scalar (cached): operand of `us_scale`."""
+        key = (float(value), str(device))
+        t = self._scalars.get(key)
+        if t is None:
+            t = self._scalars[key] = torch.tensor([value], dtype=torch.float32, device=device)
+        return t
 
     def _create(self, device: torch.device):
         if device.type != "cuda":
@@ -245,6 +263,17 @@ class _EstimatorFn(torch.autograd.Function):
         eng, keys, dev = ctx.eng, ctx.keys, ctx.dev
         B, F, T = ctx.shape
         g = _f32c(grad_out, dev)
+        # The backward GEMMs take their operands as two fp16 planes (f16x3); a mean-reduced loss puts dL/dscore around
+        # 1 / (B * F * T), which at pre-training batches is below fp16's normal range (6e-5) and would leave the hi plane a handful
+        # of bits.  Scale the incoming gradient by a power of two (exact) that brings it back to the range it has at B = 1 and undo
+        # it on everything the backward returns: loss scaling with an exact inverse.
+        scale = _grad_scale(B * F * T)
+        if scale != 1.0:
+            sc = eng.scalar(scale, dev)
+            gs = torch.empty_like(g)
+            with torch.cuda.device(dev):
+                _lib.check(eng.lib.us_scale(_dev_ptr(g), _dev_ptr(sc), _dev_ptr(gs), g.numel(), _stream()), None, "us_scale")
+            g = gs
         # one zero-filled blob, one view per parameter: a single fill instead of one per tensor
         sizes = [int(torch.Size(shape).numel()) for shape, _ in ctx.param_meta]
         offs, total = [], 0
@@ -266,6 +295,12 @@ class _EstimatorFn(torch.autograd.Function):
                                                opt(gx), opt(gmu), opt(gspk), _stream())
         ctx.tape.live = False                   # consumed (or refused) by the library either way
         _lib.check(rc, eng.handle, "us_estimator_backward")
+        if scale != 1.0:
+            inv = eng.scalar(1.0 / scale, dev)
+            with torch.cuda.device(dev):
+                for t in (blob, gx, gmu, gspk):
+                    if t is not None:
+                        _lib.check(eng.lib.us_scale(_dev_ptr(t), _dev_ptr(inv), _dev_ptr(t), t.numel(), _stream()), None, "us_scale")
         ctx.ws = None
         ctx.inputs = None
         eng.last_grad_blob = blob               # data-parallel training all-reduces this one buffer (sharding.allreduce_gradients)
