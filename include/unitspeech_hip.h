@@ -122,7 +122,11 @@ size_t us_train_workspace_bytes(us_handle h, int B, int T);
 int us_estimator_forward_train(us_handle h, const float* x, const float* mask, const float* mu, const float* t,
                                const float* spk, float* out, int B, int T, void* workspace, size_t workspace_bytes,
                                uint64_t* tape_id, us_stream stream);
-/* flags: bit 0 = the gradient buffers are already zero (e.g. views of one zero-filled blob): skips 228 fill launches. */
+/* flags: bit 0 = the gradient buffers are already zero (e.g. views of one zero-filled blob): skips 228 fill launches.
+ * Range of grad_out: the backward GEMMs split their fp32 operands into two fp16 planes, which carry full precision
+ * from about 6e-5 upwards.  The gradient of a mean-reduced loss over B*F*T elements is ~1/(B*F*T): callers that bind this entry
+ * directly should pass grad_out times a power of two that brings it to roughly 1e-4 or more and divide the returned gradients by it
+ * (the backward is linear in grad_out, so this is exact; `us_scale` does both; the Python mirror uses 2^max(0, floor(log2(B*F*T)) - 13)). */
 int us_estimator_backward(us_handle h, uint64_t tape_id, const float* grad_out, int B, int T, const char* const* keys,
                           float* const* grads, int n_grads, int flags, float* grad_x, float* grad_mu, float* grad_spk,
                           us_stream stream);

@@ -395,3 +395,48 @@ def test_finetune_graph_replay_matches_eager_iterations():
         # Adam divides by sqrt(v): where a gradient is itself rounding noise (fp32 atomics order in the weight gradients) the update is
         # +-lr in either run; such elements may differ by a fraction of a step (lr = 1e-3), the tensors as a whole may not
         assert d.max() <= 2e-4 and d.mean() <= 1e-7, (k, d.max().item(), d.mean().item())
+
+
+def test_f16x3_backward_matches_the_exact_fp32_backward_at_a_pretraining_batch():
+    """Every parameter gradient of one full-size loss over 8 crops of 176 frames: the default backward (f16x3 GEMMs for forward, data
+    and weight gradients, incoming gradient scaled by an exact power of two) against the exact-fp32 MFMA backward (US_F16X3=0) of the
+    same weights and draws.  dL/dscore is ~1e-5 here, below fp16's normal range: without the scaling the whole-gradient error is
+    1.2e-6 and single tensors reach 2.4e-5 (tools/grad_accuracy.py)."""
+    import os
+    import random
+    cfg = FULL
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(cfg, 0).items()}
+    g = np.random.Generator(np.random.Philox(key=99))
+    B, T = 8, 176
+    x0 = torch.from_numpy(g.standard_normal((B, cfg.n_feats, T), dtype=np.float32)).clamp(-1, 1).to(DEV)
+    cond = torch.from_numpy(g.standard_normal((B, cfg.n_feats, T), dtype=np.float32) * 0.5).to(DEV)
+    mask = torch.ones(B, 1, T, device=DEV)
+    spk = torch.from_numpy(g.standard_normal((B, 1, cfg.spk_emb_dim), dtype=np.float32)).to(DEV)
+    spk = spk / spk.norm(dim=-1, keepdim=True)
+
+    def grads(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
+            m.load_state_dict(sd)
+            m = m.to(DEV).train()
+            random.seed(0); torch.manual_seed(0)
+            loss, _ = m.compute_loss(x0, mask, cond, spk)
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss), {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    l_ref, ref = grads({"US_F16X3": "0"})
+    l_new, new = grads({})
+    assert len(ref) == 228 and abs(l_ref - l_new) <= 1e-6
+    whole = float(torch.sqrt(sum(((new[n] - ref[n]) ** 2).sum() for n in ref)) / torch.sqrt(sum((ref[n] ** 2).sum() for n in ref)))
+    worst = max(float((new[n] - ref[n]).norm() / (ref[n].norm() + 1e-300)) for n in ref)
+    print(f"\nf16x3 vs exact-fp32 backward, 8 crops: whole-gradient relative L2 {whole:.2e}, worst tensor {worst:.2e}")
+    assert whole <= 6e-7 and worst <= 1.2e-5
