@@ -126,7 +126,8 @@ int us_estimator_forward_train(us_handle h, const float* x, const float* mask, c
  * Range of grad_out: the backward GEMMs split their fp32 operands into two fp16 planes, which carry full precision
  * from about 6e-5 upwards.  The gradient of a mean-reduced loss over B*F*T elements is ~1/(B*F*T): callers that bind this entry
  * directly should pass grad_out times a power of two that brings it to roughly 1e-4 or more and divide the returned gradients by it
- * (the backward is linear in grad_out, so this is exact; `us_scale` does both; the Python mirror uses 2^max(0, floor(log2(B*F*T)) - 13)). */
+ * (the backward is linear in grad_out, so this is exact; `us_pow2_scale` picks the factor from the data and `us_scale` applies it and its
+ * inverse; the Python mirror does so whenever B*F*T exceeds 2^14). */
 int us_estimator_backward(us_handle h, uint64_t tape_id, const float* grad_out, int B, int T, const char* const* keys,
                           float* const* grads, int n_grads, int flags, float* grad_x, float* grad_mu, float* grad_spk,
                           us_stream stream);
@@ -148,6 +149,10 @@ int us_diffusion_loss(const float* score, const float* z_masked, const float* t,
 /* out[i] = x[i] * scalar_dev[0] (chain rule with a device-resident upstream gradient); out = x * mask[b][t] on [B,F,T]. */
 int us_scale(const float* x, const float* scalar_dev, float* out, size_t n, us_stream stream);
 int us_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, us_stream stream);
+/* scale_and_inverse[0] = 2^k with max|x| * 2^k in [2^(target_log2 - 1), 2^target_log2), [1] = 2^-k (device floats; 1, 1 for an all-zero
+ * or non-finite x): the exact loss-scaling factor for the gradient handed to us_estimator_backward (see there), chosen from the data so
+ * that it suits a summed loss as well as a mean; feed [0] and [1] to us_scale. */
+int us_pow2_scale(const float* x, size_t n, int target_log2, float* scale_and_inverse, us_stream stream);
 /* `fine_tune`'s segment crop (:458-486).  cond_x [B,F,Lu], y [B,F,Ly], attn [B,Lu,Ly]; start/count: DEVICE int64 [B]
  * (crop offset and number of valid frames min(y_length, segment_size) per item).  Writes y_cut, cond_y [B,F,segment_size]
  * (cond_y = attn_cut^T cond_x, masked) and seg_mask [B,segment_size]. */

@@ -401,7 +401,7 @@ def test_f16x3_backward_matches_the_exact_fp32_backward_at_a_pretraining_batch()
     """Every parameter gradient of one full-size loss over 8 crops of 176 frames: the default backward (f16x3 GEMMs for forward, data
     and weight gradients, incoming gradient scaled by an exact power of two) against the exact-fp32 MFMA backward (US_F16X3=0) of the
     same weights and draws.  dL/dscore is ~1e-5 here, below fp16's normal range: without the scaling the whole-gradient error is
-    1.2e-6 and single tensors reach 2.4e-5 (tools/grad_accuracy.py)."""
+    1.2e-6 and the median tensor is at 3.7e-6 (tools/grad_accuracy.py)."""
     import os
     import random
     cfg = FULL
@@ -414,7 +414,7 @@ def test_f16x3_backward_matches_the_exact_fp32_backward_at_a_pretraining_batch()
     spk = torch.from_numpy(g.standard_normal((B, 1, cfg.spk_emb_dim), dtype=np.float32)).to(DEV)
     spk = spk / spk.norm(dim=-1, keepdim=True)
 
-    def grads(env):
+    def grads(env, loss_factor=1.0):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -423,7 +423,7 @@ def test_f16x3_backward_matches_the_exact_fp32_backward_at_a_pretraining_batch()
             m = m.to(DEV).train()
             random.seed(0); torch.manual_seed(0)
             loss, _ = m.compute_loss(x0, mask, cond, spk)
-            loss.backward()
+            (loss * loss_factor).backward()
             torch.cuda.synchronize()
             return float(loss), {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
         finally:
@@ -437,6 +437,14 @@ def test_f16x3_backward_matches_the_exact_fp32_backward_at_a_pretraining_batch()
     l_new, new = grads({})
     assert len(ref) == 228 and abs(l_ref - l_new) <= 1e-6
     whole = float(torch.sqrt(sum(((new[n] - ref[n]) ** 2).sum() for n in ref)) / torch.sqrt(sum((ref[n] ** 2).sum() for n in ref)))
-    worst = max(float((new[n] - ref[n]).norm() / (ref[n].norm() + 1e-300)) for n in ref)
-    print(f"\nf16x3 vs exact-fp32 backward, 8 crops: whole-gradient relative L2 {whole:.2e}, worst tensor {worst:.2e}")
-    assert whole <= 6e-7 and worst <= 1.2e-5
+    per = sorted(float((new[n] - ref[n]).norm() / (ref[n].norm() + 1e-300)) for n in ref)
+    median, worst = per[len(per) // 2], per[-1]
+    print(f"\nf16x3 vs exact-fp32 backward, 8 crops: whole-gradient relative L2 {whole:.2e}, median tensor {median:.2e}, worst {worst:.2e}")
+    # (the worst tensors are the scalar Rezero gains, sums with heavy cancellation whose last digits also move with the order of the
+    # fp32 atomics in either run; without the scaling: whole 1.2e-6, median 3.7e-6)
+    assert whole <= 6e-7 and median <= 1.5e-6 and worst <= 1e-4
+    # the factor is taken from the data, so a caller's own (power-of-two) loss scaling changes nothing but the exponent: a summed
+    # instead of a mean-reduced loss cannot push the scaled gradients out of fp16's range
+    _, big = grads({}, loss_factor=float(2 ** 17))
+    drift = float(torch.sqrt(sum(((big[n] * 2.0 ** -17 - new[n]) ** 2).sum() for n in new)) / torch.sqrt(sum((new[n] ** 2).sum() for n in new)))
+    assert drift <= 3e-7, drift          # two runs differ by the order of their fp32 atomics only

@@ -56,6 +56,7 @@ SIGNATURES = {
     "us_diffusion_loss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "us_diffusion_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "us_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "us_pow2_scale": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "us_mul_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "us_finetune_segment": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p]),
     "us_tts_durations": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),

@@ -103,6 +103,28 @@ __global__ __launch_bounds__(64) void diffusion_loss_final_kernel(const double* 
   if (threadIdx.x == 0) loss[0] = (float)acc / (float)partial[n];
 }
 
+// out[0] = 2^k with k such that max|x| * 2^k lies in [2^(target-1), 2^target), out[1] = 2^-k; 1 and 1 for an all-zero or non-finite x.
+// One workgroup: the operand is a gradient tensor of a few hundred thousand elements, read once more by the caller's scaling pass.
+__global__ __launch_bounds__(1024) void pow2_scale_kernel(const float* __restrict__ x, long long n, int target_log2, float* __restrict__ out) {
+  __shared__ float red[16];
+  float mx = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, fabsf(x[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+    int k = 0;
+    const unsigned bits = __float_as_uint(mx);
+    const int e = (int)((bits >> 23) & 255u);
+    if (mx > 0.f && e != 255 && e != 0) k = (target_log2 - 1) - (e - 127);      // floor(log2 mx) = e - 127 for a normal float
+    k = k < -60 ? -60 : (k > 60 ? 60 : k);
+    out[0] = __uint_as_float((unsigned)(127 + k) << 23);
+    out[1] = __uint_as_float((unsigned)(127 - k) << 23);
+  }
+}
+
 __global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ out, long long n) {
   const float k = s[0];
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = x[i] * k;
@@ -332,6 +354,13 @@ int us_scale(const float* x, const float* scalar_dev, float* out, size_t n, us_s
                      (long long)n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? US_OK : fail("us_scale", e);
+}
+
+int us_pow2_scale(const float* x, size_t n, int target_log2, float* scale_and_inverse, us_stream stream) {
+  if (!x || !scale_and_inverse || n == 0 || target_log2 < -100 || target_log2 > 100) return bad("us_pow2_scale: bad argument");
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, (long long)n, target_log2, scale_and_inverse);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? US_OK : fail("us_pow2_scale", e);
 }
 
 int us_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, us_stream stream) {

@@ -115,13 +115,14 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
-def _grad_scale(n_elements: int) -> float:
-    """Power of two applied to the gradient entering `us_estimator_backward` (and removed from its results): 1 up to 2^14 elements in
-    the loss's mean (one 176-frame crop), doubling with every doubling beyond.  UNITSPEECH_GRAD_SCALE_LOG2 overrides the exponent."""
+def _scale_gradient(n_elements: int) -> bool:
+    """Whether the gradient entering `us_estimator_backward` is brought into fp16's normal range by a power of two first (and the
+    results divided by it): beyond 2^14 elements under the loss's mean, i.e. more than one 176-frame crop, where the unscaled backward
+    starts to lose precision (one crop measures 4.7e-7 against the exact-fp32 backward without it and skips the two extra passes).
+    UNITSPEECH_GRAD_SCALE=0/1 forces it off / on."""
     import os
-    e = os.environ.get("UNITSPEECH_GRAD_SCALE_LOG2")
-    k = int(e) if e is not None else max(0, int(math.floor(math.log2(max(n_elements, 1)))) - 13)
-    return float(2 ** min(k, 24))
+    e = os.environ.get("UNITSPEECH_GRAD_SCALE")
+    return bool(int(e)) if e is not None else n_elements > (1 << 14)
 
 
 class _Engine:
@@ -139,18 +140,9 @@ class _Engine:
         self.handle = C.c_void_p()
         self.device = None
         self.last_grad_blob = None
-        self._scalars = {}
         self.versions = {}
         self._key_meta = {}         # key -> (bytes key, ctypes shape array, shape)
         self.workspace = None
-
-    def scalar(self, value: float, device) -> torch.Tensor:
-        """Device-resident fp32 scalar (cached): operand of `us_scale`."""
-        key = (float(value), str(device))
-        t = self._scalars.get(key)
-        if t is None:
-            t = self._scalars[key] = torch.tensor([value], dtype=torch.float32, device=device)
-        return t
 
     def _create(self, device: torch.device):
         if device.type != "cuda":
@@ -267,11 +259,13 @@ class _EstimatorFn(torch.autograd.Function):
         # 1 / (B * F * T), which at pre-training batches is below fp16's normal range (6e-5) and would leave the hi plane a handful
         # of bits.  Scale the incoming gradient by a power of two (exact) that brings it back to the range it has at B = 1 and undo
         # it on everything the backward returns: loss scaling with an exact inverse.
-        scale = _grad_scale(B * F * T)
-        if scale != 1.0:
-            sc = eng.scalar(scale, dev)
+        # The factor comes from the data (largest |g| to [2^-7, 2^-6)), so a summed loss or a caller's own loss scaling is as safe as a mean.
+        scaled = _scale_gradient(B * F * T)
+        if scaled:
+            sc = torch.empty(2, dtype=torch.float32, device=dev)          # {2^k, 2^-k}
             gs = torch.empty_like(g)
             with torch.cuda.device(dev):
+                _lib.check(eng.lib.us_pow2_scale(_dev_ptr(g), g.numel(), -6, _dev_ptr(sc), _stream()), None, "us_pow2_scale")
                 _lib.check(eng.lib.us_scale(_dev_ptr(g), _dev_ptr(sc), _dev_ptr(gs), g.numel(), _stream()), None, "us_scale")
             g = gs
         # one zero-filled blob, one view per parameter: a single fill instead of one per tensor
@@ -295,8 +289,8 @@ class _EstimatorFn(torch.autograd.Function):
                                                opt(gx), opt(gmu), opt(gspk), _stream())
         ctx.tape.live = False                   # consumed (or refused) by the library either way
         _lib.check(rc, eng.handle, "us_estimator_backward")
-        if scale != 1.0:
-            inv = eng.scalar(1.0 / scale, dev)
+        if scaled:
+            inv = sc[1:]
             with torch.cuda.device(dev):
                 for t in (blob, gx, gmu, gspk):
                     if t is not None:
