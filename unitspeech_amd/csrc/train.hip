@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
 // (channel >> 2) & 3 so that both the converting writes and the fragment reads spread over the banks) and every wave reads its
 // fragments from there with ds_read_b128: each value is split once per workgroup, not once per wave that uses it.
 // Gradients are small (a mean-reduced loss puts dL/dy around 1e-5, below fp16's normal range), so the workgroup first takes the
-// absolute maximum of ITS slice of gy and multiplies by the power of two that brings it to [2^14, 2^15): exact, undone on the
-// accumulators at the end.  hi = fp16(v), lo = fp16((v - hi) * 2^11); C = C_hh + 2^-11 C_x as in conv_igemm.hip.
+// absolute maximum of (a sample of) ITS slice of gy and multiplies by the power of two that brings it to [2^10, 2^11): exact, undone
+// on the accumulators at the end.  hi = fp16(v), lo = fp16((v - hi) * 2^11); C = C_hh + 2^-11 C_x as in conv_igemm.hip.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 constexpr int kWgKP16 = 16;
 
@@ -272,7 +272,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
   float mx = 0.f;
   {
     const int rl = tid >> 5, ch = (tid & 31) * 4;       // 8 pixel rows per pass, a channel quad per thread
-    for (int m = m_lo + rl; m < m_hi; m += 8) {
+    // every eighth row of eight: the full slice was read nine times over by the tap workgroups (0.5 ms of a level-0 launch at 32 crops);
+    // the target below leaves 2^5 of headroom for what the sample misses (and the conversion saturates, it does not wrap)
+    for (int m = m_lo + rl; m < m_hi; m += 64) {
       const int yy = m / a.Ws, xx = m - yy * a.Ws;
       const f32x4 v = *reinterpret_cast<const f32x4*>(gy_b + ((long long)(a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * a.gy_ld + co0 + ch);
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -283,9 +285,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
     __syncthreads();
     mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   }
-  // 2^(14 - floor(log2 mx)), kept inside the normal range; an all-zero (or non-finite) slice is left unscaled
+  // 2^(10 - floor(log2 mx)), kept inside the normal range; an all-zero (or non-finite) slice is left unscaled
   int e2 = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
-  int se = 14 - e2;
+  int se = 10 - e2;
   if (!(mx > 0.f) || e2 > 127) se = 0;
   se = se < -100 ? -100 : (se > 100 ? 100 : se);
   const float g_scale = __uint_as_float((unsigned)(127 + se) << 23), g_unscale = __uint_as_float((unsigned)(127 - se) << 23);
@@ -350,10 +352,14 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
     // this wave's pieces of stage st have landed; after the barrier everybody's have, and everybody has read the image of st-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (st + 1 < nstage) dma(m_lo + (st + 1) * kWgKP16, (st + 1) & 1);      // its buffer was converted at stage st-1
-    convert(st & 1);
+#ifndef US_WGRAD_ABL
+#define US_WGRAD_ABL 0      // timing ablations (wrong results): 1 conversion only at stage 0, 2 no fragment reads / MFMAs, 4 no loads in the loop
+#endif
+    if (st + 1 < nstage && !(US_WGRAD_ABL & 4)) dma(m_lo + (st + 1) * kWgKP16, (st + 1) & 1);      // its buffer was converted at stage st-1
+    if (!(US_WGRAD_ABL & 1) || st == 0) convert(st & 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (US_WGRAD_ABL & 2) continue;
     half8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
