@@ -212,6 +212,8 @@ struct WgradArgs {
   int B, Hin, Win, Cin, Hout, Wout, Cout;
   int Hs, Ws, oy0, ox0, ostep, istride, ntaps;
   int chunk;             // output pixels per workgroup (multiple of 8)
+  int vchunk;            // f16x3 kernel, shared gw (gw_bstride == 0): pixels per workgroup of the range CONCATENATED over the B items
+                         // (0 = per-item chunks as above); set by launch_wgrad
   int overwrite;         // 1: gw holds garbage; legal only when every element has exactly one writer (launch_wgrad_single_writer)
   unsigned long long dy_bits, dx_bits, wtap_bits;
   void set_tap(int i, int dy, int dx, int wtap) {

@@ -251,18 +251,24 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
   const int Ms = a.Hs * a.Ws;
   const int chunks_per_item = (Ms + a.chunk - 1) / a.chunk;
   const WgIdx wi = wgrad_index();
-  const int b = wi.bx / chunks_per_item;
-  const int m_lo = (wi.bx % chunks_per_item) * a.chunk;
-  int m_hi = m_lo + a.chunk;
-  if (m_hi > Ms) m_hi = Ms;
+  // Pixel range of this workgroup.  vchunk: positions of the B items laid end to end, so that a workgroup of a deep level (220 pixels
+  // per crop, 2,304 tile-taps) sums over many crops in registers before its 64 KB of atomic adds -- at 32 crops those were 0.9 ms of
+  // every 1024-channel launch (one workgroup per crop, tile and tap: 1.2 GB of atomics against the chip's ~1.3 TB/s).
+  const bool vmode = a.vchunk > 0;
+  const int b = vmode ? 0 : wi.bx / chunks_per_item;
+  const int m_lo = vmode ? wi.bx * a.vchunk : (wi.bx % chunks_per_item) * a.chunk;
+  const int m_end = vmode ? a.B * Ms : Ms;
+  int m_hi = m_lo + (vmode ? a.vchunk : a.chunk);
+  if (m_hi > m_end) m_hi = m_end;
   const int nci = a.Cin / 128;
   const int co0 = (wi.by / nci) * 128, ci0 = (wi.by % nci) * 128;
   const int tap = wi.tap;
   const int dy = (int)((a.dy_bits >> (4 * tap)) & 15) - 8;
   const int dx = (int)((a.dx_bits >> (4 * tap)) & 15) - 8;
   const int wt_i = (int)((a.wtap_bits >> (4 * tap)) & 15);
-  const unsigned gy_bytes = (unsigned)a.Hout * (unsigned)a.Wout * (unsigned)a.gy_ld * 4u;
-  const unsigned x_bytes = (unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.x_ld * 4u;
+  const unsigned gy_item = (unsigned)a.Hout * (unsigned)a.Wout * (unsigned)a.gy_ld * 4u, x_item = (unsigned)a.Hin * (unsigned)a.Win * (unsigned)a.x_ld * 4u;
+  const unsigned gy_bytes = vmode ? gy_item * (unsigned)a.B : gy_item;      // vmode: one descriptor over all items (< 2^31 bytes, host-checked)
+  const unsigned x_bytes = vmode ? x_item * (unsigned)a.B : x_item;
   const float* gy_b = a.gy + (long long)b * a.Hout * a.Wout * a.gy_ld;
   const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc((void*)gy_b, 0, (int)gy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_x =
@@ -274,9 +280,11 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
     const int rl = tid >> 5, ch = (tid & 31) * 4;       // 8 pixel rows per pass, a channel quad per thread
     // every eighth row of eight: the full slice was read nine times over by the tap workgroups (0.5 ms of a level-0 launch at 32 crops);
     // the target below leaves 2^5 of headroom for what the sample misses (and the conversion saturates, it does not wrap)
-    for (int m = m_lo + rl; m < m_hi; m += 64) {
+    for (int vm = m_lo + rl; vm < m_hi; vm += 64) {
+      const int bi = vm / Ms, m = vm - bi * Ms;        // (bi = 0 outside vmode)
       const int yy = m / a.Ws, xx = m - yy * a.Ws;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(gy_b + ((long long)(a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * a.gy_ld + co0 + ch);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(gy_b + (long long)bi * (gy_item / 4) +
+                                                      ((long long)(a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * a.gy_ld + co0 + ch);
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
 #pragma unroll
@@ -300,14 +308,15 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = wave * 4 + 2 * j;
-      const int m = stage_m0 + r + lrow;
+      const int vm = stage_m0 + r + lrow;
       unsigned goff = gy_bytes, xoff = x_bytes;      // out of range: zeros
-      if (m < m_hi) {
+      if (vm < m_hi) {
+        const int bi = vm / Ms, m = vm - bi * Ms;    // (bi = 0 outside vmode)
         const int yy = m / a.Ws, xx = m - yy * a.Ws;
-        goff = ((unsigned)((a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * (unsigned)a.gy_ld + (unsigned)(co0 + lch)) * 4u;
+        goff = (unsigned)bi * gy_item + ((unsigned)((a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * (unsigned)a.gy_ld + (unsigned)(co0 + lch)) * 4u;
         const int iy = yy * a.istride + dy, ix = xx * a.istride + dx;
         if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
-          xoff = ((unsigned)(iy * a.Win + ix) * (unsigned)a.x_ld + (unsigned)(ci0 + lch)) * 4u;
+          xoff = (unsigned)bi * x_item + ((unsigned)(iy * a.Win + ix) * (unsigned)a.x_ld + (unsigned)(ci0 + lch)) * 4u;
       }
       wg_blds16(rsrc_g, goff, As + r * 128);
       wg_blds16(rsrc_x, xoff, Bs + r * 128);
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
       }
   }
   float* gw = a.gw + (long long)b * a.gw_bstride + (long long)wt_i * a.Cout * a.Cin;
-  const bool single = chunks_per_item == 1 && (a.B == 1 || a.gw_bstride != 0);    // the only writer of these elements
+  const bool single = vmode ? gridDim.x == 1 : (chunks_per_item == 1 && (a.B == 1 || a.gw_bstride != 0));    // the only writer of these elements
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -427,6 +436,22 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     static int use_f16 = -1;       // US_WGRAD_F16=0: the exact-fp32 MFMA form
     if (use_f16 < 0) { const char* e = getenv("US_WGRAD_F16"); use_f16 = e ? atoi(e) : 1; }
     if (use_f16) {
+      WgradArgs a2 = a;
+      static int target_wgs = -1;
+      if (target_wgs < 0) { const char* e = getenv("US_WGRAD_WGS"); target_wgs = e ? atoi(e) : 1536; }
+      const long long V = (long long)a.B * Ms;
+      if (a.B > 1 && a.gw_bstride == 0 && !a.overwrite && (long long)a.B * a.Hout * a.Wout * a.gy_ld * 4 < (1LL << 31) &&
+          (long long)a.B * a.Hin * a.Win * a.x_ld * 4 < (1LL << 31) && V < (1LL << 30)) {
+        // one pixel range over all items, cut so that ~target workgroups result (never finer than the per-item rule would cut one item)
+        const long long others = (long long)g2.y * g2.z;
+        long long nch = (target_wgs + others - 1) / others;
+        if (nch < 1) nch = 1;
+        long long vc = (V + nch - 1) / nch;
+        if (vc < a.chunk) vc = a.chunk;
+        vc = (vc + 15) / 16 * 16;
+        a2.vchunk = (int)vc;
+        g2.x = (unsigned)((V + vc - 1) / vc);
+      }
       const int lds16 = (2 * 2 * kWgKP16 * 128 + 2 * 128 * 16) * (int)sizeof(float);
       static bool attr16_set = false;
       if (!attr16_set) {
@@ -434,7 +459,7 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr16_set = true;
       }
-      hipLaunchKernelGGL(wgrad_f16_kernel, g2, dim3(256), lds16, s, a);
+      hipLaunchKernelGGL(wgrad_f16_kernel, g2, dim3(256), lds16, s, a2);
       return hipGetLastError();
     }
     hipLaunchKernelGGL(wgrad_lds_kernel, g2, dim3(256), lds, s, a);
