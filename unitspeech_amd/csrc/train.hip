@@ -899,46 +899,80 @@ hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float
 // first layer (2 input channels) weight gradients: gw3[co][ci][ky][kx] += sum_p gy[p][co]*in2[p+d][ci];
 // gw1[co][ci] += sum_p gr[p][co]*in2[p][ci]     (reference layouts, written with atomics)
 // ---------------------------------------------------------------------------------------------------
+constexpr int kFcwMaxT = 2048;      // frames per item the LDS patch of first_conv_wgrad_kernel holds (3 rows x (T + 2) x 2 channels)
 __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const float* __restrict__ in2, const float* __restrict__ gy,
-                                                               const float* __restrict__ gr, int F, int T, int C,
+                                                               const float* __restrict__ gr, int F, int T, int C, int Bp, int ipb,
                                                                float* __restrict__ gw3, float* __restrict__ gw1) {
-  // one block = one mel row of one item; thread = output channel (looped), registers hold the 18 + 2 partial sums
-  const int b = blockIdx.y, f = blockIdx.x;
-  for (int co = threadIdx.x; co < C; co += 256) {
+  // one block = one mel row of `ipb` items.  The three input rows it touches sit in LDS, zero-padded at both ends and for rows outside
+  // the image, so the frame loop has no branches and the compiler can keep several frames' gradient loads in flight (the loop used to
+  // wait for one pair of loads per frame: 1.2 ms at 32 crops, 0.11 ms at one, for 0.2 GB of traffic).  Thread = (output channel,
+  // frame parity); the two parities meet in LDS before the atomics.
+  extern __shared__ float fsm[];                    // patch [3][T + 2][2], then the parity-1 partial sums [C][20]
+  float* patch = fsm;
+  float* part = fsm + 3 * (T + 2) * 2;
+  const int f = blockIdx.x;
+  const int half = threadIdx.x >> 7;                // frame parity (C <= 128 per pass)
+  for (int c0 = 0; c0 < C; c0 += 128) {
+    const int co = c0 + (threadIdx.x & 127);
     float a3[18], a1[2];
 #pragma unroll
     for (int i = 0; i < 18; ++i) a3[i] = 0.f;
     a1[0] = a1[1] = 0.f;
-    for (int t = 0; t < T; ++t) {
-      const long long p = ((long long)b * F + f) * T + t;
-      const float g = gy[p * C + co], r = gr[p * C + co];
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int ff = f + ky - 1;
-        if (ff < 0 || ff >= F) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int tt = t + kx - 1;
-          if (tt < 0 || tt >= T) continue;
-          const float* ip = in2 + (((long long)b * F + ff) * T + tt) * 2;
-          a3[ky * 3 + kx] += g * ip[0];
-          a3[9 + ky * 3 + kx] += g * ip[1];
-        }
-      }
-      const float* ip = in2 + p * 2;
-      a1[0] += r * ip[0];
-      a1[1] += r * ip[1];
+    // several items per block (ipb): every block ends in 20 atomics per channel on the SAME 2,560 addresses, which at 32 crops was most
+    // of the kernel's time
+    for (int b = blockIdx.y * ipb; b < (blockIdx.y + 1) * ipb && b < Bp; ++b) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * (T + 2) * 2; i += 256) {
+      const int c = i & 1, xx = (i >> 1) % (T + 2), yy = (i >> 1) / (T + 2);
+      const int ff = f + yy - 1, tt = xx - 1;
+      patch[i] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? in2[(((long long)b * F + ff) * T + tt) * 2 + c] : 0.f;
     }
+    __syncthreads();
+    if (co < C) {
+      const float* gyp = gy + (((long long)b * F + f) * T) * C + co;
+      const float* grp = gr + (((long long)b * F + f) * T) * C + co;
+#pragma unroll 4
+      for (int t = half; t < T; t += 2) {
+        const float g = gyp[(long long)t * C], r = grp[(long long)t * C];
 #pragma unroll
-    for (int i = 0; i < 18; ++i) atomicAdd(&gw3[co * 18 + i], a3[i]);
-    atomicAdd(&gw1[co * 2], a1[0]);
-    atomicAdd(&gw1[co * 2 + 1], a1[1]);
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float* ip = patch + ((ky * (T + 2)) + t + kx) * 2;      // frame t + kx - 1 of row f + ky - 1
+            a3[ky * 3 + kx] = fmaf(g, ip[0], a3[ky * 3 + kx]);
+            a3[9 + ky * 3 + kx] = fmaf(g, ip[1], a3[9 + ky * 3 + kx]);
+          }
+        const float* ip = patch + ((T + 2) + t + 1) * 2;
+        a1[0] = fmaf(r, ip[0], a1[0]);
+        a1[1] = fmaf(r, ip[1], a1[1]);
+      }
+    }
+    }   // items of this block
+    if (half == 1 && co < C) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) part[(co - c0) * 20 + i] = a3[i];
+      part[(co - c0) * 20 + 18] = a1[0];
+      part[(co - c0) * 20 + 19] = a1[1];
+    }
+    __syncthreads();
+    if (half == 0 && co < C) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) atomicAdd(&gw3[co * 18 + i], a3[i] + part[(co - c0) * 20 + i]);
+      atomicAdd(&gw1[co * 2], a1[0] + part[(co - c0) * 20 + 18]);
+      atomicAdd(&gw1[co * 2 + 1], a1[1] + part[(co - c0) * 20 + 19]);
+    }
+    __syncthreads();
   }
 }
 
 hipError_t launch_first_conv_wgrad(const float* in2, const float* gy, const float* gr, int Bp, int F, int T, int C, float* gw3,
                                    float* gw1, hipStream_t s) {
-  hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(F, Bp), dim3(256), 0, s, in2, gy, gr, F, T, C, gw3, gw1);
+  if (T > kFcwMaxT) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)3 * (T + 2) * 2 + 128 * 20) * sizeof(float);
+  int ipb = (int)(((long long)Bp * F + 639) / 640);       // items per block: about 640 blocks (2.5 per CU)
+  if (ipb < 1) ipb = 1;
+  if (ipb > 8) ipb = 8;
+  hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(F, (Bp + ipb - 1) / ipb), dim3(256), lds, s, in2, gy, gr, F, T, C, Bp, ipb, gw3, gw1);
   return hipGetLastError();
 }
 
