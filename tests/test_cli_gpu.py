@@ -47,3 +47,14 @@ def test_pretrain_step_bench_runs(tmp_path):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["batch_per_gpu"] == 2 and d["value"] > 0 and np.isfinite(d["last_loss"])
     assert set(d["ms_breakdown"]) == {"fwd", "bwd", "allreduce", "optim"}
+
+
+def test_frontend_bench_runs():
+    """bench_frontend.py (text Encoder + DurationPredictor per utterance, with its oracle comparison): sane JSON, parity inside the bench."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_frontend.py"), "--symbols", "60", "--iters", "3"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["finite"] and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port"
+    assert d["max_abs_diff_vs_oracle"] <= 2e-5
