@@ -900,7 +900,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (a.f16 == 1 && a.ntaps == 1 && a.istride == 1 && !a.bias && !a.add) a.splitk_ws = nullptr;    // Winograd-domain GEMMs
     if (tm == 0 && g_f16_tm > 0) tm = g_f16_tm;
     if (tm == 0) {
-      if (a.f16 == 1) {
+      if (a.f16 == 1 && a.ntaps > 1) {
+        tm = 64;      // a direct convolution whose producer wrote the two-plane form: same rule as the in-kernel split below
+      } else if (a.f16 == 1) {
         // Winograd-domain GEMMs (all items of a frequency in one M range): the largest tile that still fills the chip
         const long long per256 = (long long)((a.Hs * a.Ws + 255) / 256) * nt * a.B;
         tm = per256 >= 384 ? 256 : 128;

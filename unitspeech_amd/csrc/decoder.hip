@@ -108,6 +108,7 @@ struct us_decoder {
   long long wino_fuse_min_wgs_small = 200;       // US_WINO_FUSE_MIN_WGS_SMALL: ... for matrices of at most
   long long wino_fuse_small_kn = 512 * 256;      // US_WINO_FUSE_SMALL_KN elements per frequency
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
+  bool presplit = true;      // US_PRESPLIT=0: block1's GroupNorm output stays fp32 for the direct block2 convolution (split in the kernel)
   bool xcd_z = true;         // US_XCD_Z=0: the Winograd-domain GEMMs dealt to the XCDs by tile only, not by whole frequencies (A/B)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
                             // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
@@ -536,10 +537,16 @@ hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, 
   return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn, w.w->wino_f16);
 }
 
-hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats) {
-  if (w.w->wino.p && e.b->wino_v) return conv3x3_wino(e, w, in, in_ld, level, out, out_ld, stats);
+// in_split: `in` is the two-plane fp16 form written by gn_apply(out_split) (direct f16x3 convolutions only: direct_presplit())
+hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, double* stats,
+                   bool in_split = false) {
+  if (w.w->wino.p && e.b->wino_v) return in_split ? hipErrorInvalidValue : conv3x3_wino(e, w, in, in_ld, level, out, out_ld, stats);
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
+  if (in_split) {
+    if (a.f16 != 2) return hipErrorInvalidValue;
+    a.f16 = 1;
+  }
   a.ntaps = 9;
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx);
@@ -591,7 +598,8 @@ hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
 }
 
 hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* stats, const Slot* g, const Slot* bta,
-                    const float* temb, const float* res, int res_ld, bool res_masked, bool post_mask, float* out, int out_ld) {
+                    const float* temb, const float* res, int res_ld, bool res_masked, bool post_mask, float* out, int out_ld,
+                    bool out_split = false) {
   GnApplyArgs a;
   memset(&a, 0, sizeof a);
   a.y = y; a.y_ld = C;
@@ -601,6 +609,7 @@ hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* 
   a.temb = temb; a.temb_ld = C;
   a.res = res; a.res_ld = res_ld; a.res_masked = res_masked ? 1 : 0;
   a.post_mask = post_mask ? 1 : 0;
+  a.out_split = out_split ? 1 : 0;
   a.out = out; a.out_ld = out_ld;
   a.B = e.Bp; a.H = e.h->cfg.n_feats >> level; a.W = e.T >> level; a.C = C;
   return launch_gn_apply(a, e.s);
@@ -611,6 +620,13 @@ hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* 
     hipError_t _e = (expr);               \
     if (_e != hipSuccess) return _e;      \
   } while (0)
+
+// block1's output has ONE consumer, block2's convolution: where that runs as a direct f16x3 convolution (level 0), gn_apply writes the
+// two-plane fp16 form and the convolution skips its in-kernel split (-15 % on the level-0 3x3 in tools/conv_bench).  `tmp`: a buffer
+// of the activation's size other than the GroupNorm's input (the planes of a channel quad overlap its neighbour's fp32 input).
+inline bool direct_presplit(EvalCtx& e, const ConvW& w, int C, int tmp_ld) {
+  return e.h->presplit && !(w.w->wino.p && e.b->wino_v) && w.w->direct_f16 && C % 8 == 0 && tmp_ld == C;
+}
 
 // ResnetBlock (unitspeech/unitspeech.py:58-75).  `in` must already be masked.  mask_out: the result is only consumed
 // through `x * mask` (next ResnetBlock / concat), so the mask is applied to what is stored; false when the consumer
@@ -633,8 +649,13 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
     CK(conv3x3_wino(e, r.c2, S1, r.cout, l, S2, r.cout, st2, &g));
   } else {
     // block1 output + time embedding, pre-masked for block2's `x * mask` (:54)
-    CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, true, S1, r.cout));
-    CK(conv3x3(e, r.c2, S1, r.cout, l, S2, r.cout, st2));
+    if (direct_presplit(e, r.c2, r.cout, out_ld) && out != in) {
+      CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, true, out, r.cout, true));      // `out` is free until the end
+      CK(conv3x3(e, r.c2, out, r.cout, l, S2, r.cout, st2, true));
+    } else {
+      CK(gn_apply(e, S1, l, r.cout, st1, r.g1, r.b1, tproj, nullptr, 0, false, true, S1, r.cout));
+      CK(conv3x3(e, r.c2, S1, r.cout, l, S2, r.cout, st2));
+    }
   }
   if (r.has_res) {
     CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, nullptr, 0, false, false, out, out_ld));
@@ -736,8 +757,13 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
         g.mask = e.mask; g.mask_ld = e.T; g.mask_step = 1; g.mask_bmod = e.Bm;
         CK(conv3x3_wino(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2, &g));
       } else {
-        CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, true, b.S1[0], c));
-        CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
+        if (direct_presplit(e, r.c2, c, c)) {      // as in resnet(): P[0], this block's output buffer, holds the two-plane form meanwhile
+          CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, true, b.P[0], c, true));
+          CK(conv3x3(e, r.c2, b.P[0], c, 0, b.S2[0], c, st2, true));
+        } else {
+          CK(gn_apply(e, b.S1[0], 0, c, st1, r.g1, r.b1, b.tproj + b.tproj_off[r.index], nullptr, 0, false, true, b.S1[0], c));
+          CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
+        }
       }
       CK(gn_apply(e, b.S2[0], 0, c, st2, r.g2, r.b2, nullptr, b.Q[0], c, false, true, b.P[0], c));
     } else {
@@ -916,6 +942,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (const char* wf = getenv("US_F16X3_DGRAD")) h->f16x3_dgrad = atoi(wf) != 0;
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
   if (const char* wf = getenv("US_XCD_Z")) h->xcd_z = atoi(wf) != 0;
+  if (const char* wf = getenv("US_PRESPLIT")) h->presplit = atoi(wf) != 0;
   h->build();
   {
     int max_cin = 2 * h->C.back();

@@ -139,6 +139,9 @@ struct GnApplyArgs {
   const float* temb; int temb_ld;                          // optional [B][temb_ld] per-channel addend
   const float* res; int res_ld; int res_masked;            // optional residual (times mask when res_masked)
   int post_mask;
+  int out_split;                                           // out receives the two-plane fp16 form (per 8 channels: 8 hi | 8 lo, same bytes
+                                                           // as fp32) that a direct f16x3 convolution takes as a pre-split A operand;
+                                                           // out must not alias y (a quad's lo plane lands on its neighbour's input)
   float* out; int out_ld;
   int B, H, W, C;
 };

@@ -230,7 +230,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
       o += a.res_masked ? rr * m : rr;
     }
     if (a.post_mask) o *= m;
-    *reinterpret_cast<f32x4*>(ob + p * a.out_ld + c) = o;
+    if (a.out_split) {
+      // hi = fp16(x), lo = fp16((x - hi) * 2^11), clamped to the fp16 range as the Winograd input transforms do (wino.hip)
+      typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+      half4_t hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float x = fminf(fmaxf(o[k], -65504.f), 65504.f);
+        const _Float16 h = (_Float16)x;
+        hi[k] = h;
+        lo[k] = (_Float16)fminf(fmaxf((x - (float)h) * 2048.f, -65504.f), 65504.f);
+      }
+      _Float16* oh = reinterpret_cast<_Float16*>(ob + p * a.out_ld) + 2 * (c & ~7) + (c & 7);
+      *reinterpret_cast<half4_t*>(oh) = hi;
+      *reinterpret_cast<half4_t*>(oh + 8) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(ob + p * a.out_ld + c) = o;
+    }
     if (fixed_quad) {
       p += rpi;
       w += wstep;
@@ -242,6 +258,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
   if (a.C % 4 != 0 || a.C % kGroups != 0 || a.y_ld % 4 != 0 || a.out_ld % 4 != 0 || (a.res && a.res_ld % 4 != 0))
     return hipErrorInvalidValue;
+  if (a.out_split && (a.C % 8 != 0 || a.out_ld % 8 != 0 || a.out == a.y)) return hipErrorInvalidValue;
   long long total = (long long)a.H * a.W * (a.C / 4);
   int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
   if (blocks < 1) blocks = 1;
