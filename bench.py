@@ -59,6 +59,7 @@ def parse(argv=None):
                          "multi-GPU run on a one-GPU box (RCCL refuses two ranks on one device); the throughput it prints is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="diffusion steps timed on the host CPU")
+    ap.add_argument("--profile-steps", type=int, default=2, help="untimed decodes after the timed region whose conv launches are event-sampled")
     a = ap.parse_args(argv)
     cb, cg = CONFIGS[a.config] if a.config else (1, 1)
     if a.batch is None:
@@ -170,17 +171,41 @@ class HipWorkload:
 
 
 def pmc_traffic():
-    """HBM bytes per conv launch from the committed counter summary (separate rocprofv3 --pmc passes, tools/pmc_traffic.py), with
-    the commit it was measured at: a constant of that commit, not of the run that prints it."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_traffic.json"):
+    """HBM-side bytes from the committed counter summary (separate rocprofv3 --pmc passes, tools/pmc_collect.sh + pmc_summary.py), with
+    the commit it was measured at: constants of that commit, not of the run that prints them.  Returns (bytes per conv launch, bytes of
+    ALL kernels per score-network evaluation at B' = 3, 80x1024, source)."""
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
                 d = json.load(open(path))
-                return d.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "commit": d.get("commit")}
+                return (d.get("hbm_bytes_per_launch"), d.get("all_kernels_hbm_side_bytes_per_evaluation"),
+                        {"file": "profiles/" + name, "commit": d.get("commit")})
             except Exception:
                 pass
-    return None, None
+    return None, None, None
+
+
+def algorithmic_bytes_per_eval(n_params, Bp, T):
+    """the weights once (fp32) + B' * T * 964 B of tensor I/O (x, mu [80, T] and the mask in, the score out)."""
+    return 4.0 * n_params + float(Bp) * T * 964.0
+
+
+def rank_census(dist, rank, world, device, backend):
+    """What the process group actually is, gathered from every rank AFTER init_process_group: the line must not repeat WORLD_SIZE."""
+    if dist is None:
+        name = torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu"
+        return 1, [{"rank": 0, "device": str(device), "name": name}]
+    me = {"rank": dist.get_rank(), "device": str(device), "name": torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu",
+          "host": os.uname().nodename, "pid": os.getpid()}
+    if device.type == "cuda":
+        try:
+            me["uuid"] = str(torch.cuda.get_device_properties(device).uuid)
+        except Exception:
+            pass
+    got = [None] * world
+    dist.all_gather_object(got, me)
+    return dist.get_world_size(), got
 
 
 def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, device=None):
@@ -196,10 +221,19 @@ def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, de
             kw = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
+    if backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks over RCCL need {world} visible GPUs, this process sees {torch.cuda.device_count()} "
+                         "(--rehearse-on-one-gpu runs the N-rank path on one device over gloo)")
+    n_ranks, ranks = rank_census(dist, rank, world, device, backend)
+    if n_ranks != world:
+        raise SystemExit(f"the process group has {n_ranks} ranks, the launcher announced {world}")
+
     cfg = a.cfg if getattr(a, "cfg", None) is not None else DecoderConfig()
     B, T, N = a.batch, a.frames, a.diffusion_steps
     # rank 0 generates the synthetic checkpoint; the others receive it as ONE packed 476.6 MB fp32 blob over RCCL
-    sd = broadcast_state_dict(cfg, synthetic_state_dict(cfg, 0) if rank == 0 else None, rank, world, device)
+    timing = {}
+    sd = broadcast_state_dict(cfg, synthetic_state_dict(cfg, 0) if rank == 0 else None, rank, world, device, timing=timing)
+    n_params = int(sum(v.numel() for v in sd.values()))
     wl = workload_cls(cfg, sd, device, a, rank)
     del sd
 
@@ -207,20 +241,32 @@ def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, de
     for _ in range(a.warmup):
         out = wl.step()
     wl.sync()
-    wl.profile_begin()
 
+    # timed region: exactly `steps` decodes between barrier + synchronize on both sides; no event sampling inside
     if dist is not None:
         dist.barrier()
     wl.sync()
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        s0 = time.perf_counter()
         out = wl.step()
+        wl.sync()
+        per_step.append(time.perf_counter() - s0)
     wl.sync()
+    busy = time.perf_counter() - t0                 # this rank's own K steps, before it waits for the others
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, world, device)
+    own = time.perf_counter() - t0
+    elapsed = max_over_ranks(own, world, device)
+    slowest, fastest = max_over_ranks(busy, world, device), -max_over_ranks(-busy, world, device)
+    median_step = max_over_ranks(float(np.median(per_step)) if per_step else 0.0, world, device)
     assert out is None or torch.isfinite(out).all(), "non-finite decoder output"
+    # per-launch times for the roofline object: separate, untimed decodes with the library's event sampling switched on
+    wl.profile_begin()
+    for _ in range(max(1, min(a.steps, a.profile_steps))):
+        wl.step()
+    wl.sync()
     prof = wl.profile_end()
 
     res = None
@@ -240,7 +286,8 @@ def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, de
         flops_per_launch = prof["conv_flops"] / launches
         eq = (flops_per_launch / (avg_ms * 1e-3)) / 1e12 if avg_ms > 0 else 0.0
         f16_n = prof.get("f16_launches", 0)
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_all, traffic_src = pmc_traffic()
+        alg_bytes = algorithmic_bytes_per_eval(n_params, 3, 1024)      # at the shape the counters were collected on (B' = 3, T = 1024)
         if f16_n > 0:
             f16_avg_ms = prof["f16_ms"] / f16_n
             f16_exec_per_launch = 3.0 * prof["f16_flops"] / f16_n
@@ -255,6 +302,8 @@ def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, de
             basis = "executed MFMA FLOPs per conv_igemm launch (Winograd F(2x2,3x3) GEMMs at their reduced count)"
         roofline = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_all_kernels_per_eval": traffic_all, "algorithmic_bytes_per_eval": alg_bytes,
+                    "traffic_over_algorithmic": (traffic_all / alg_bytes) if traffic_all else None,
                     "flops_per_launch": per_launch, "avg_launch_ms": avg, "launches_sampled": n_l, "flops_basis": basis,
                     "fp32_equivalent": {"achieved": eq, "peak": PEAK_F32_MFMA_TFLOPS, "frac": eq / PEAK_F32_MFMA_TFLOPS,
                                         "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches_sampled": launches,
@@ -265,7 +314,11 @@ def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, de
                     # whole_job_tflops is the direct-convolution count of SURVEY.md 8(d) over wall time
                     "whole_job_tflops": flops_step * world / (ms_per_step * 1e-3) / 1e12}
         res = {"metric": "mel-frames/sec @ 50 diffusion steps, 80x1024", "value": value, "unit": "mel-frames/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+               "n_gpus": n_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+               "ms_per_step_median": 1e3 * median_step, "value_at_median": world * B * T / median_step if median_step > 0 else None,
+               "rccl_ranks": {"backend": backend if world > 1 else None, "world_size": n_ranks, "ranks": ranks},
+               "broadcast_ms": timing.get("broadcast_ms"), "broadcast_bytes": timing.get("bytes"),
+               "rank_busy_s": {"min": fastest, "max": slowest, "note": "each rank's own K steps before the closing barrier"},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "dtype_note": "fp32 storage and fp32 accumulation everywhere; GEMM products at fp32 accuracy as f16x3 (two fp16 planes per "
                              "operand, three fp16 MFMA products; per-evaluation error vs fp64 at the fp32 reference's level)",

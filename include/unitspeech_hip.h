@@ -47,7 +47,24 @@ typedef struct us_config {
 
 /* UnitSpeech(...) constructor.  Allocates the packed device weight store (not the weights' values). */
 int us_decoder_create(us_handle* out, const us_config* cfg);
+/* The same with creation flags.  US_CREATE_EXACT_FP32: every GEMM of this handle runs on the exact-fp32 matrix instruction
+ * (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain) instead of the f16x3 form (three fp16 MFMA products of two-plane split operands,
+ * fp32-accurate for operands inside the fp16 range): the path for tensors beyond +-65504, see us_range_status. */
+enum { US_CREATE_EXACT_FP32 = 1 };
+int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags);
 int us_decoder_destroy(us_handle h);
+
+/* f16x3 operand range.  The reference computes in plain fp32 (unitspeech/unitspeech.py:46-96); the default handle forms its GEMM
+ * products from fp16 planes, which represent |x| < 65520.  A larger operand is never clamped: it becomes an infinity (the affected
+ * outputs are non-finite, as loud as an overflow can be; a NaN input stays a NaN, as in the reference) and the split that met it
+ * ORs a bit into a per-handle device word: US_RANGE_ACT for an activation, Winograd-domain value or gradient, US_RANGE_WEIGHT for a
+ * weight at load time (or a folded attention weight).  us_range_status copies the word to *status (0 = every result since the last
+ * reset is fp32-accurate), optionally clears it, and WAITS for `stream`; the _async form only enqueues the copy into the caller's
+ * (pinned) host word.  A caller that sees a non-zero status repeats the call on a US_CREATE_EXACT_FP32 handle -- the Python mirror
+ * does so by itself (unitspeech_amd/unitspeech.py: _Engine.range_status, UnitSpeech._run_checked). */
+enum { US_RANGE_ACT = 1, US_RANGE_WEIGHT = 2 };
+int us_range_status(us_handle h, unsigned* status, int reset, us_stream stream);
+int us_range_status_async(us_handle h, unsigned* status_host, int reset, us_stream stream);
 
 /* `load_state_dict` for one tensor: `key` is the reference state_dict key (e.g.
  * "estimator.downs.0.0.block1.block.0.weight"), `data` a device pointer in the reference's own layout
@@ -123,11 +140,11 @@ int us_estimator_forward_train(us_handle h, const float* x, const float* mask, c
                                const float* spk, float* out, int B, int T, void* workspace, size_t workspace_bytes,
                                uint64_t* tape_id, us_stream stream);
 /* flags: bit 0 = the gradient buffers are already zero (e.g. views of one zero-filled blob): skips 228 fill launches.
- * Range of grad_out: the backward GEMMs split their fp32 operands into two fp16 planes, which carry full precision
- * from about 6e-5 upwards.  The gradient of a mean-reduced loss over B*F*T elements is ~1/(B*F*T): callers that bind this entry
- * directly should pass grad_out times a power of two that brings it to roughly 1e-4 or more and divide the returned gradients by it
- * (the backward is linear in grad_out, so this is exact; `us_pow2_scale` picks the factor from the data and `us_scale` applies it and its
- * inverse; the Python mirror does so whenever B*F*T exceeds 2^14). */
+ * Range of grad_out: any.  The backward GEMMs split their fp32 operands into two fp16 planes, which carry full
+ * precision from about 6e-5 upwards, while the gradient of a mean-reduced loss over B*F*T elements is ~1/(B*F*T) and a caller's loss
+ * weight or accumulation factor comes on top: the entry point itself multiplies grad_out by the power of two that brings its largest
+ * magnitude to [2^-7, 2^-6) (chosen on the device from the data), runs the pass, and multiplies everything it returns by the inverse
+ * -- exact, because the pass is linear in grad_out.  grad_out is not modified. */
 int us_estimator_backward(us_handle h, uint64_t tape_id, const float* grad_out, int B, int T, const char* const* keys,
                           float* const* grads, int n_grads, int flags, float* grad_x, float* grad_mu, float* grad_spk,
                           us_stream stream);
@@ -150,8 +167,8 @@ int us_diffusion_loss(const float* score, const float* z_masked, const float* t,
 int us_scale(const float* x, const float* scalar_dev, float* out, size_t n, us_stream stream);
 int us_mul_mask(const float* x, const float* mask, float* out, int B, int F, int T, us_stream stream);
 /* scale_and_inverse[0] = 2^k with max|x| * 2^k in [2^(target_log2 - 1), 2^target_log2), [1] = 2^-k (device floats; 1, 1 for an all-zero
- * or non-finite x): the exact loss-scaling factor for the gradient handed to us_estimator_backward (see there), chosen from the data so
- * that it suits a summed loss as well as a mean; feed [0] and [1] to us_scale. */
+ * or non-finite x): an exact, data-driven scaling factor (what us_estimator_backward applies to its grad_out internally); feed [0] and
+ * [1] to us_scale. */
 int us_pow2_scale(const float* x, size_t n, int target_log2, float* scale_and_inverse, us_stream stream);
 /* `fine_tune`'s segment crop (:458-486).  cond_x [B,F,Lu], y [B,F,Ly], attn [B,Lu,Ly]; start/count: DEVICE int64 [B]
  * (crop offset and number of valid frames min(y_length, segment_size) per item).  Writes y_cut, cond_y [B,F,segment_size]
@@ -173,9 +190,9 @@ int us_tts_align(const float* cond_x, const float* w_ceil, const float* x_mask, 
 
 /* ---- the two learned modules of the conditioning producer, inference -------------------------------
  * `Encoder` (unitspeech/encoder.py:253-308; text encoder and unit encoder are two instances) and `DurationPredictor`
- * (unitspeech/duration_predictor.py:24-63, reverse=True).  Same conventions as the decoder handle, except that the
- * activation scratch belongs to the handle (grown on demand with hipMalloc, so these calls cannot be stream-captured
- * before their first eager run at the same size).  Dropout is the identity (eval mode); `n_contentvec > 0`
+ * (unitspeech/duration_predictor.py:24-63, reverse=True).  Same conventions as the decoder handle: the caller owns the
+ * activation scratch (us_frontend_workspace_bytes), nothing is allocated or freed by a forward call, and a call made while
+ * another device than the handle's is current is refused (US_EINVAL).  Dropout is the identity (eval mode); `n_contentvec > 0`
  * (encoder.py:281: a Linear instead of the Embedding) and `heads_share=False` are not built -- no configuration of the
  * reference uses them (conf/hydra_config.py:85-116). */
 typedef struct us_frontend* us_frontend_handle;
@@ -205,12 +222,13 @@ const char* us_frontend_weight_key(us_frontend_handle h, int i);
 const char* us_frontend_last_error(us_frontend_handle h);
 /* `Encoder.forward(x, x_lengths)` (:294-308): ids [B,L] int64, lengths [B] int64 (device) ->
  * mu_x [B,n_feats,L], x [B,n_channels,L], x_mask [B,1,L]. */
+size_t us_frontend_workspace_bytes(us_frontend_handle h, int B, int L);
 int us_encoder_forward(us_frontend_handle h, const int64_t* ids, const int64_t* lengths, float* mu_x, float* x, float* x_mask, int B, int L,
-                       us_stream stream);
+                       void* workspace, size_t workspace_bytes, us_stream stream);
 /* `DurationPredictor.forward(x, x_mask, w=None, g=g, reverse=True)` (:47-63): x [B,in_channels,L], x_mask [B,1,L],
  * g [B,1,spk_emb_dim] (NULL iff spk_emb_dim == 0) -> logw [B,1,L]. */
 int us_duration_predictor_forward(us_frontend_handle h, const float* x, const float* x_mask, const float* g, float* logw, int B, int L,
-                                  us_stream stream);
+                                  void* workspace, size_t workspace_bytes, us_stream stream);
 
 /* ---- one building block of the score network on its own (parity tests against per-module reference outputs) ---------
  * prefix: the module's state_dict prefix ("estimator.downs.1.1", "estimator.downs.1.2", "estimator.downs.1.3",

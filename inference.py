@@ -109,7 +109,7 @@ def main():
             phoneme=phoneme, phoneme_lengths=phoneme_lengths, spk_emb=spk_emb, text_encoder=text_encoder,
             duration_predictor=duration_predictor, num_downsamplings_in_unet=n_down, diffusion_steps=args.diffusion_steps,
             length_scale=args.length_scale, text_gradient_scale=args.text_gradient_scale, spk_gradient_scale=args.spk_gradient_scale,
-            mel_range=(float(mel_min), float(mel_max)))
+            mel_range=(mel_min, mel_max))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     frames = mel.shape[-1]

@@ -82,7 +82,7 @@ def test_c_abi_key_tables_match_the_state_dict_layout():
         assert lib.us_encoder_create(C.byref(h), C.byref(c)) == 0
         keys = [lib.us_frontend_weight_key(h, i).decode() for i in range(lib.us_frontend_num_weights(h))]
         assert keys == list(encoder_state_shapes(ecfg)) and lib.us_frontend_weight_key(h, len(keys)) is None
-        assert lib.us_duration_predictor_forward(h, None, None, None, None, 1, 1, None) == -1        # wrong kind of handle: EINVAL
+        assert lib.us_duration_predictor_forward(h, None, None, None, None, 1, 1, None, 0, None) == -1        # wrong kind of handle: EINVAL
         assert lib.us_frontend_destroy(h) == 0
         h = C.c_void_p()
         c = _lib.us_duration_config(dcfg.in_channels, dcfg.filter_channels, dcfg.kernel_size, dcfg.spk_emb_dim)
@@ -199,9 +199,9 @@ def test_c_abi_reports_unknown_keys_wrong_shapes_and_missing_weights():
     assert lib.us_frontend_load_weight(h, b"conv_1.weight", w.data_ptr(), bad, 3, None) == -3            # ESHAPE
     assert lib.us_frontend_load_weight(h, b"conv_1.weight", w.data_ptr(), shp, 3, None) == 0
     x, m, g, out = (torch.zeros(n, device="cuda") for n in (16 * 4, 4, 12, 4))
-    assert lib.us_duration_predictor_forward(h, x.data_ptr(), m.data_ptr(), g.data_ptr(), out.data_ptr(), 1, 4, None) == -4      # EWEIGHTS
+    assert lib.us_duration_predictor_forward(h, x.data_ptr(), m.data_ptr(), g.data_ptr(), out.data_ptr(), 1, 4, None, 0, None) == -4      # EWEIGHTS
     assert b"has not been loaded" in lib.us_frontend_last_error(h)
-    assert lib.us_duration_predictor_forward(h, x.data_ptr(), m.data_ptr(), None, out.data_ptr(), 1, 4, None) == -1               # g missing
+    assert lib.us_duration_predictor_forward(h, x.data_ptr(), m.data_ptr(), None, out.data_ptr(), 1, 4, None, 0, None) == -1               # g missing
     torch.cuda.synchronize()
     assert lib.us_frontend_destroy(h) == 0
 

@@ -1,0 +1,306 @@
+"""GPU parity tests added in round 3 (all through the C ABI).
+
+* The f16x3 operand range (VERDICT r2 "What's weak" 1): a tensor beyond the fp16 range that meets a split-precision GEMM
+  is never clamped -- the handle reports it (`us_range_status`), the affected results are non-finite, a NaN stays a NaN, and the
+  Python mirror repeats an inference call on the exact-fp32 engine, which matches the oracle.  Reference semantics: plain fp32
+  everywhere, `unitspeech/unitspeech.py:46-96`.
+* The loss scaling of the backward now lives inside `us_estimator_backward` (data-driven power of two for ANY magnitude of grad_out).
+* loss and every parameter gradient of a pre-training batch (8 crops of 176 frames, full size) against the oracle's
+  `loss_t` under torch autograd on the CPU (`train_STEP1.py:381`, `unitspeech/unitspeech.py:393-411`).
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_oracle as O
+from unitspeech_amd import DecoderConfig, UnitSpeech, _lib, synthetic_inputs, synthetic_state_dict
+from unitspeech_amd.unitspeech import RangeError
+
+pytestmark = pytest.mark.gpu
+
+FULL = DecoderConfig()
+DEV = "cuda:0"
+
+
+def G(d):
+    return {k: (torch.from_numpy(np.asarray(v)) if np.asarray(v).dtype.kind != "U" else str(v)) for k, v in d.items()}
+
+
+def l1(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().mean().item()
+
+
+def build(sd_np, exact=False, train=False):
+    cfg = FULL
+    m = UnitSpeech(cfg.n_feats, cfg.dim, list(cfg.dim_mults), cfg.beta_min, cfg.beta_max, cfg.pe_scale, cfg.spk_emb_dim)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    m.exact = exact
+    m = m.to(DEV)
+    return m.train() if train else m.eval()
+
+
+@pytest.fixture(scope="module")
+def sd_np():
+    return synthetic_state_dict(FULL, 0)
+
+
+def _debug_block(eng, kind, prefix, level, x_nchw, T, cout):
+    """One `Block` of the score network through us_debug_block on the given engine; returns (out [B,C,H,W], range status)."""
+    lib = eng.lib
+    B, _, H, W = x_nchw.shape
+    x = x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.empty(B, H, W, cout, device=DEV)
+    ws = torch.empty(int(lib.us_workspace_bytes(eng.handle, B, T)), dtype=torch.uint8, device=DEV)
+    m = torch.ones(B, T, device=DEV)
+    rc = lib.us_debug_block(eng.handle, kind, prefix.encode(), level, C.c_void_p(x.data_ptr()), C.c_void_p(m.data_ptr()), None,
+                            C.c_void_p(out.data_ptr()), B, T, C.c_void_p(ws.data_ptr()), ws.numel(), None)
+    _lib.check(rc, eng.handle, "us_debug_block")
+    st = C.c_uint(0)
+    _lib.check(lib.us_range_status(eng.handle, C.byref(st), 1, None), eng.handle, "us_range_status")
+    return out.permute(0, 3, 1, 2).cpu(), int(st.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# range: the C ABI reports, never clamps
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("level,prefix,C_", [(0, "estimator.downs.0.1", 128), (1, "estimator.downs.1.1", 256)])
+def test_block_with_activations_beyond_the_fp16_range_is_reported_and_exact_on_the_fp32_handle(sd_np, level, prefix, C_):
+    """`Block` (conv3x3 -> GroupNorm -> Mish, :46-55) on an input of magnitude 1e5: level 0 runs the direct f16x3 convolution (split
+    inside the kernel), level 1 the Winograd form (V = B^T d B split by the input transform).  Default handle: status US_RANGE_ACT and
+    a non-finite output (the old behaviour was a finite, silently clamped one); exact-fp32 handle: status 0 and the oracle's values.
+    A well-scaled input leaves the status at 0 on both."""
+    model = build(sd_np)
+    T = 64
+    H, W = FULL.n_feats >> level, T >> level
+    g = np.random.Generator(np.random.Philox(key=5 + level))
+    x = torch.from_numpy(g.standard_normal((2, C_, H, W), dtype=np.float32))
+    sd = O.to_torch(sd_np)
+    ones = torch.ones(2, 1, 1, W)
+    for scale in (1.0, 1e5):
+        xs = x * scale
+        ref = O.block(sd, prefix + ".block1", xs, ones)
+        eng = model._sync(torch.device(DEV))
+        got, st = _debug_block(eng, 0, prefix, level, xs, T, C_)
+        eng_x = model._sync(torch.device(DEV), exact=True)
+        got_x, st_x = _debug_block(eng_x, 0, prefix, level, xs, T, C_)
+        e_x = l1(got_x, ref)
+        print(f"\nlevel {level}, |x| ~ {scale:g}: f16x3 status {st}, exact status {st_x}, exact L1 vs oracle {e_x:.2e}"
+              + (f", f16x3 L1 {l1(got, ref):.2e}" if st == 0 else f", f16x3 finite share {torch.isfinite(got).float().mean().item():.3f}"))
+        assert st_x == 0 and e_x <= 2e-6 * max(1.0, ref.abs().mean().item())
+        if scale == 1.0:
+            assert st == 0 and l1(got, ref) <= 2e-6
+        else:
+            assert st & _lib.US_RANGE_ACT
+            assert not torch.isfinite(got).all()             # loud: an overflow is an infinity, not 65504
+
+
+def test_nan_and_tiny_operands(sd_np):
+    """A NaN activation stays a NaN (the clamp used to launder it into 65504) and does not count as a range event; operands around
+    1e-6 (the floor of the lo plane) keep fp32-level accuracy through the GroupNorm that follows."""
+    model = build(sd_np)
+    T, level, prefix, C_ = 64, 0, "estimator.downs.0.1", 128
+    H, W = FULL.n_feats, T
+    g = np.random.Generator(np.random.Philox(key=11))
+    x = torch.from_numpy(g.standard_normal((1, C_, H, W), dtype=np.float32))
+    eng = model._sync(torch.device(DEV))
+    xn = x.clone()
+    xn[0, 3, 10, 20] = float("nan")
+    got, st = _debug_block(eng, 0, prefix, level, xn, T, C_)
+    assert st == 0 and torch.isnan(got).any()
+    sd = O.to_torch(sd_np)
+    ones = torch.ones(1, 1, 1, W)
+    xt = x * 1e-6
+    ref = O.block(sd, prefix + ".block1", xt, ones)
+    got, st = _debug_block(eng, 0, prefix, level, xt, T, C_)
+    eng_x = model._sync(torch.device(DEV), exact=True)
+    got_x, _ = _debug_block(eng_x, 0, prefix, level, xt, T, C_)
+    e, e_x = l1(got, ref), l1(got_x, ref)
+    print(f"\n|x| ~ 1e-6: f16x3 L1 vs oracle {e:.2e}, exact-fp32 handle {e_x:.2e}, mean |out| {ref.abs().mean().item():.3f}")
+    assert st == 0 and e <= 2e-6 and e_x <= 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# range: the Python mirror repeats the call on the exact-fp32 engine
+# ---------------------------------------------------------------------------------------------------------------
+def test_estimator_with_a_1e5_activation_falls_back_to_the_exact_engine_and_matches_the_oracle(sd_np):
+    """Weights whose last Upsample (`ups.2.3`, :21) emits values around 1e5-1e6: they feed the final Block's direct f16x3 convolution.  The
+    default engine reports the range event, the mirror warns and repeats the evaluation on the exact-fp32 engine; the result is
+    the oracle's to 2e-6 of the output scale.  (GroupNorm makes the final Block scale-invariant, so the reference's own fp32
+    arithmetic is well conditioned here.)"""
+    sd = dict(sd_np)
+    sd["estimator.ups.2.3.conv.weight"] = (sd_np["estimator.ups.2.3.conv.weight"] * np.float32(1e6)).astype(np.float32)
+    sd["estimator.ups.2.3.conv.bias"] = (sd_np["estimator.ups.2.3.conv.bias"] * np.float32(1e6)).astype(np.float32)
+    model = build(sd)
+    T, B = 64, 2
+    inp = G(synthetic_inputs(FULL, B, T, seed=3, lengths=[T, T - 8]))
+    t = torch.tensor([0.3, 0.8])
+    taps = {}
+    ref = O.estimator_forward(O.to_torch(sd), inp["z"], inp["mask"], inp["cond"], t, inp["spk_emb"], FULL.pe_scale, taps=taps)
+    big = (taps["ups.2"] * inp["mask"].unsqueeze(1)).abs()             # what the final Block's convolution reads (`x * mask`, :54)
+    assert (big > 65520).float().mean().item() > 0.1 and torch.isfinite(ref).all()
+    args = [inp[k].to(DEV) for k in ("z", "mask", "cond")] + [t.to(DEV), inp["spk_emb"].to(DEV)]
+    with pytest.warns(RuntimeWarning, match="exact-fp32"), torch.no_grad():
+        out = model.estimator(*args)
+    e = l1(out, ref)
+    scale = ref.abs().mean().item()
+    print(f"\n1e5 activation: exact-engine fall-back L1 vs oracle {e:.2e} (mean |out| {scale:.3f}, max |ups.2| {taps['ups.2'].abs().max().item():.3g})")
+    assert torch.isfinite(out).all() and e <= 2e-6 * max(1.0, scale)
+    # with the check switched off the caller gets what the default engine computed: non-finite where the overflow mattered
+    model.range_check = False
+    with torch.no_grad():
+        raw = model.estimator(*args)
+    assert not torch.isfinite(raw).all()
+    assert model.range_status() & _lib.US_RANGE_ACT
+    # the sampler takes the same route
+    model.range_check = True
+    with pytest.warns(RuntimeWarning, match="exact-fp32"):
+        dec = model(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), inp["spk_emb"].to(DEV), 2, 1.0, 1.0, rng="philox", seed=1)
+    model.exact = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        dec_x = model(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), inp["spk_emb"].to(DEV), 2, 1.0, 1.0, rng="philox", seed=1)
+    assert torch.isfinite(dec).all() and torch.equal(dec, dec_x)
+
+
+def test_weight_beyond_the_fp16_range_moves_the_model_to_the_exact_engine(sd_np):
+    """One convolution weight of 3e5 at a corner tap (so that U = G g G^T of the Winograd pack carries it undamped): the pack reports
+    US_RANGE_WEIGHT, the first call is repeated on the exact engine and later calls go there directly."""
+    sd = dict(sd_np)
+    w = sd_np["estimator.downs.1.1.block1.block.0.weight"].copy()
+    w[3, 5, 0, 0] = 3e5
+    sd["estimator.downs.1.1.block1.block.0.weight"] = w
+    model = build(sd)
+    T, B = 64, 1
+    inp = G(synthetic_inputs(FULL, B, T, seed=4))
+    t = torch.tensor([0.5])
+    ref = O.estimator_forward(O.to_torch(sd), inp["z"], inp["mask"], inp["cond"], t, inp["spk_emb"], FULL.pe_scale)
+    args = [inp[k].to(DEV) for k in ("z", "mask", "cond")] + [t.to(DEV), inp["spk_emb"].to(DEV)]
+    with pytest.warns(RuntimeWarning, match="exact-fp32"), torch.no_grad():
+        out = model.estimator(*args)
+    assert l1(out, ref) <= 2e-6 * max(1.0, ref.abs().mean().item())
+    assert model._get_engine(False).weights_out_of_range
+    with warnings.catch_warnings(), torch.no_grad():
+        warnings.simplefilter("error")                       # no second detour through the default engine
+        out2 = model.estimator(*args)
+    assert torch.equal(out, out2)
+
+
+def test_training_reports_a_range_event_one_call_late(sd_np):
+    """Training calls cannot be repeated transparently (the tape is consumed): the status is copied asynchronously after every backward
+    and the next forward raises RangeError."""
+    sd = dict(sd_np)
+    sd["estimator.ups.2.3.conv.weight"] = (sd_np["estimator.ups.2.3.conv.weight"] * np.float32(1e6)).astype(np.float32)
+    model = build(sd, train=True)
+    T = 64
+    inp = G(synthetic_inputs(FULL, 1, T, seed=8))
+    x0, mask, cond, spk = (inp[k].to(DEV) for k in ("z", "mask", "cond", "spk_emb"))
+    torch.manual_seed(0)
+    loss, _ = model.compute_loss(x0, mask, cond, spk)
+    loss.backward()
+    torch.cuda.synchronize()
+    with pytest.raises(RangeError):
+        model.compute_loss(x0, mask, cond, spk)
+    model.exact = True                                        # the documented way out
+    model.zero_grad(set_to_none=True)                         # (the first pass left non-finite gradients behind)
+    torch.manual_seed(0)
+    loss, _ = model.compute_loss(x0, mask, cond, spk)
+    loss.backward()
+    bad = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    assert torch.isfinite(loss) and not bad, (float(loss), bad[:8])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# loss scaling inside us_estimator_backward
+# ---------------------------------------------------------------------------------------------------------------
+def _crops(B, T, key):
+    g = np.random.Generator(np.random.Philox(key=key))
+    x0 = torch.from_numpy(g.standard_normal((B, FULL.n_feats, T), dtype=np.float32)).clamp(-1, 1)
+    cond = torch.from_numpy(g.standard_normal((B, FULL.n_feats, T), dtype=np.float32) * 0.5)
+    lengths = [T - 8 * (b % 3) for b in range(B)]
+    mask = torch.zeros(B, 1, T)
+    for b, n in enumerate(lengths):
+        mask[b, 0, :n] = 1.0
+    spk = torch.from_numpy(g.standard_normal((B, 1, FULL.spk_emb_dim), dtype=np.float32))
+    spk = spk / spk.norm(dim=-1, keepdim=True)
+    t = torch.from_numpy(g.uniform(0.05, 0.95, size=(B,)).astype(np.float32))
+    z = torch.from_numpy(g.standard_normal((B, FULL.n_feats, T), dtype=np.float32))
+    return x0, mask, cond, spk, t, z
+
+
+class _ReplayRandn:
+    def __init__(self, draws):
+        self.draws, self.i = list(draws), 0
+
+    def __enter__(self):
+        self.orig = torch.randn
+        torch.randn = self
+        return self
+
+    def __exit__(self, *a):
+        torch.randn = self.orig
+
+    def __call__(self, *shape, **kw):
+        d = self.draws[self.i]
+        self.i += 1
+        return d.to(device=kw.get("device", d.device), dtype=kw.get("dtype", d.dtype))
+
+
+def _hip_grads(sd_np, x0, mask, cond, spk, t, z, exact=False, loss_factor=1.0):
+    m = build(sd_np, exact=exact, train=True)
+    with _ReplayRandn([z.to(DEV)]):
+        loss, _ = m.loss_t(x0.to(DEV), mask.to(DEV), cond.to(DEV), t.to(DEV), spk.to(DEV))
+    (loss * loss_factor).backward()
+    torch.cuda.synchronize()
+    assert m.range_status() == 0
+    return float(loss), {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _rel(new, ref, show=3):
+    whole = float(torch.sqrt(sum(((new[n] - ref[n]) ** 2).sum() for n in ref)) / torch.sqrt(sum((ref[n] ** 2).sum() for n in ref)))
+    per = sorted((float((new[n] - ref[n]).norm() / (ref[n].norm() + 1e-300)), n) for n in ref)
+    print("\n  worst tensors: " + ", ".join(f"{n} {e:.1e} (|ref| {float(ref[n].norm()):.1e}, {ref[n].numel()} el.)" for e, n in per[-show:]))
+    return whole, per[len(per) // 2][0], per[-1][0]
+
+
+def test_backward_is_insensitive_to_the_magnitude_of_the_incoming_gradient(sd_np):
+    """one 176-frame crop with the loss multiplied by 1e-3 (a loss-term weight, 1 / accumulation steps, an outer scaler)
+    put dL/dscore at ~7e-8, far below fp16's normal range, and the old element-count gate never rescaled B = 1.  The entry point now
+    scales by a data-driven power of two itself: the gradients are those of the exact-fp32 backward times 1e-3."""
+    args = _crops(1, 176, key=21)
+    _, ref = _hip_grads(sd_np, *args, exact=True)
+    _, small = _hip_grads(sd_np, *args, loss_factor=1e-3)
+    small = {n: g * 1e3 for n, g in small.items()}
+    whole, median, worst = _rel(small, ref)
+    print(f"\nloss x 1e-3 at one crop: whole-gradient relative L2 vs exact fp32 {whole:.2e}, median tensor {median:.2e}, worst {worst:.2e}")
+    # (the worst tensors are the scalar Rezero gains: one-element sums with heavy cancellation, |g| down to 2e-6 here, whose last digits
+    # also move with the order of the fp32 atomics in either run)
+    assert len(ref) == 228 and whole <= 6e-7 and median <= 1.5e-6 and worst <= 1e-3
+
+
+def test_pretraining_batch_loss_and_every_gradient_vs_oracle_autograd(sd_np):
+    """SURVEY 8(f4) at the size it names per GPU slice: 8 crops of 176 frames, full-size decoder, ragged lengths.  Oracle: `loss_t`
+    (`oracle/decoder_oracle.py`, pinned to the reference) under torch autograd on the CPU in fp32.  Columns: the default backward
+    (f16x3) and the exact-fp32 handle, each against the oracle; bar: whole-gradient relative L2 <= 1e-6."""
+    B, T = 8, 176
+    x0, mask, cond, spk, t, z = _crops(B, T, key=33)
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch(sd_np).items()}
+    loss_ref, _ = O.loss_t(sd, x0, mask, cond, t, spk, z, FULL.n_feats, FULL.beta_min, FULL.beta_max, FULL.pe_scale)
+    loss_ref.backward()
+    ref = {k: v.grad.detach().double() for k, v in sd.items() if v.grad is not None and k.startswith("estimator.")}
+    assert len(ref) == 228
+    l_new, new = _hip_grads(sd_np, x0, mask, cond, spk, t, z)
+    l_x, ex = _hip_grads(sd_np, x0, mask, cond, spk, t, z, exact=True)
+    new = {k: new[k] for k in ref}
+    ex = {k: ex[k] for k in ref}
+    w_new, med_new, worst_new = _rel(new, ref)
+    w_x, med_x, worst_x = _rel(ex, ref)
+    print(f"\n8 x 176 crops vs oracle autograd: loss {float(loss_ref):.7f} / f16x3 {l_new:.7f} / exact {l_x:.7f}; "
+          f"whole-gradient relative L2 f16x3 {w_new:.2e} (median tensor {med_new:.2e}, worst {worst_new:.2e}), "
+          f"exact-fp32 {w_x:.2e} (median {med_x:.2e}, worst {worst_x:.2e})")
+    assert abs(l_new - float(loss_ref)) <= 2e-6 * max(1.0, abs(float(loss_ref)))
+    assert abs(l_x - float(loss_ref)) <= 2e-6 * max(1.0, abs(float(loss_ref)))
+    assert w_new <= 1e-6 and w_x <= 1e-6
+    assert med_new <= 3e-6 and med_x <= 3e-6

@@ -135,6 +135,15 @@ def test_bench_rank_function_two_gloo_ranks(tmp_path):
     assert r0["ms_per_step"] >= 40.0
     assert abs(r0["value"] - 2 * 3 * 64 * 4 / (r0["ms_per_step"] * 4e-3)) <= 1e-6 * r0["value"]
     assert "roofline" in r0 and "cpu_baseline" not in r0
+    # what the process group says about itself (not WORLD_SIZE): both ranks, their devices, the broadcast that fed them
+    rr = r0["rccl_ranks"]
+    assert rr["world_size"] == 2 and rr["backend"] == "gloo" and sorted(x["rank"] for x in rr["ranks"]) == [0, 1]
+    assert len({x["pid"] for x in rr["ranks"]}) == 2 and all(x["device"] == "cpu" for x in rr["ranks"])
+    assert r0["broadcast_ms"] is not None and r0["broadcast_ms"] > 0 and r0["broadcast_bytes"] == 4 * sum(int(np.prod(v.shape)) for v in synthetic_state_dict(CFG, 0).values())
+    # rank 0 sleeps 20 ms per step, rank 1 40 ms: the straggler is visible, and the median sits next to the mean
+    assert r0["rank_busy_s"]["min"] < 0.75 * r0["rank_busy_s"]["max"] <= 0.75 * 1e-3 * r0["ms_per_step"] * 4 * 1.01
+    assert r0["ms_per_step_median"] >= 40.0 and abs(r0["ms_per_step_median"] - r0["ms_per_step"]) <= 0.25 * r0["ms_per_step"]
+    assert r0["roofline"]["algorithmic_bytes_per_eval"] > 0
 
 
 def test_bench_spawns_its_own_ranks_and_refuses_mismatch(monkeypatch):

@@ -15,6 +15,7 @@ ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--bp", type=int, default=3)
 ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--wino-min-level", type=int, default=1, help="levels >= this run their 3x3 convs as Winograd (US_WINO_MIN_LEVEL)")
+ap.add_argument("--wino-narrow", action="store_true", help="US_WINO_NARROW=1: Winograd also where cout <= dim (the last up level)")
 a = ap.parse_args()
 
 F, T, BP = 80, a.frames, a.bp
@@ -38,8 +39,8 @@ def conv(name, l_out_pixels, cin, cout, taps, wino=False):
 
 def resnet(name, l, cin, cout, first=False):
     if not first:
-        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=l >= WMIN)
-    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=l >= WMIN)
+        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=l >= WMIN and (cout > a.dim or a.wino_narrow))
+    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=l >= WMIN and (cout > a.dim or a.wino_narrow))
     if cin != cout and not first:
         conv(f"{name}.res 1x1 {cin}->{cout} L{l}", npx(l), cin, cout, 1)
 

@@ -106,7 +106,19 @@ if sched and n % len(sched) == 0 and n:
         res["conv_launches"].append(o)
     res["hbm_bytes_per_launch"] = tot_bytes / len(sched)
     res["conv_hbm_side_bytes_per_evaluation"] = tot_bytes
+# every kernel of the score network, per evaluation: the trace holds as many evaluations as final_conv_kernel dispatches; weight packs,
+# table copies and torch's own kernels (set-up, once per handle) are left out
+n_eval = max(calls.get("final_conv_kernel", 0), 1)
+setup = ("pack_", "copy_table", "copy_rows", "fill_", "at::", "__amd_rocclr", "l2_normalize", "mul_mask", "finish_mel", "Cijk")
+all_bytes = 0.0
+for k, o in res["kernels"].items():
+    if any(t in k for t in setup):
+        continue
+    all_bytes += o.get("hbm_side_bytes_per_dispatch (2*FETCH_SIZE + WRITE_SIZE, KiB -> B)", 0.0) * o.get("dispatches", 0)
+res["evaluations_in_trace"] = n_eval
+res["all_kernels_hbm_side_bytes_per_evaluation"] = all_bytes / n_eval
 json.dump(res, open(out, "w"), indent=1)
+print(f"all kernels of one evaluation: {all_bytes / n_eval / 1e9:.2f} GB HBM-side ({n_eval} evaluations in the trace)")
 print(f"{len(res['kernels'])} kernels; conv launches per evaluation: {len(sched) if sched else '?'}; "
       f"conv HBM-side bytes per evaluation: {res.get('conv_hbm_side_bytes_per_evaluation', 0) / 1e9:.2f} GB")
 for k, o in list(res["kernels"].items())[:8]:

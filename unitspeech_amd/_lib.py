@@ -11,6 +11,8 @@ import threading
 from . import _build
 
 US_OK = 0
+US_CREATE_EXACT_FP32 = 1
+US_RANGE_ACT, US_RANGE_WEIGHT = 1, 2
 ERRORS = {-1: "EINVAL", -2: "ENOKEY", -3: "ESHAPE", -4: "EWEIGHTS", -5: "EWORKSPACE", -6: "EHIP"}
 
 
@@ -31,7 +33,10 @@ class us_duration_config(C.Structure):
 # symbol -> (restype, argtypes); must list every function declared in include/unitspeech_hip.h
 SIGNATURES = {
     "us_decoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(us_config)]),
+    "us_decoder_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(us_config), C.c_uint]),
     "us_decoder_destroy": (C.c_int, [C.c_void_p]),
+    "us_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
+    "us_range_status_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "us_decoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     "us_decoder_flush_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "us_decoder_num_weights": (C.c_int, [C.c_void_p]),
@@ -68,8 +73,9 @@ SIGNATURES = {
     "us_frontend_num_weights": (C.c_int, [C.c_void_p]),
     "us_frontend_weight_key": (C.c_char_p, [C.c_void_p, C.c_int]),
     "us_frontend_last_error": (C.c_char_p, [C.c_void_p]),
-    "us_encoder_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
-    "us_duration_predictor_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p]),
+    "us_frontend_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "us_encoder_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "us_duration_predictor_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "us_debug_block": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "us_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -159,7 +159,7 @@ hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, 
 // weff[b] in the conv kernel's packed layout [1 tap][128/bk][C][bk]:
 //   weff[co][h*32+d] = sum_e wout[co][h*32+e] * ctx[b][h][d][e]
 __global__ __launch_bounds__(256) void attn_weff_kernel(const float* __restrict__ ctx, const float* __restrict__ wout,
-                                                        float* __restrict__ weff, int C, int bk, int f16) {
+                                                        float* __restrict__ weff, int C, int bk, int f16, unsigned* range_flag) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= C * kHidden) return;
@@ -176,16 +176,19 @@ __global__ __launch_bounds__(256) void attn_weff_kernel(const float* __restrict_
   } else {          // two interleaved fp16 planes (conv_igemm_kernel F16 operand format, bk = 32)
     _Float16* w16 = reinterpret_cast<_Float16*>(weff + o);
     const int k = hd % 32;
-    const float c = fminf(fmaxf(acc, -65504.f), 65504.f);
-    const _Float16 h = (_Float16)c;
+    us_half h, l;
+    bool over = false;
+    split_f16x3(acc, h, l, over);
     w16[(k / 8) * 16 + k % 8] = h;
-    w16[(k / 8) * 16 + 8 + k % 8] = (_Float16)fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+    w16[(k / 8) * 16 + 8 + k % 8] = l;
+    range_report(range_flag, over, kRangeWeight);
   }
 }
 
 hipError_t launch_attn_weff(const float* ctx, const float* wout, float* weff, int B, int C, int bk, hipStream_t s, bool f16) {
   if (f16 && bk != 32) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(attn_weff_kernel, dim3((C * kHidden + 255) / 256, B), dim3(256), 0, s, ctx, wout, weff, C, bk, f16 ? 1 : 0);
+  hipLaunchKernelGGL(attn_weff_kernel, dim3((C * kHidden + 255) / 256, B), dim3(256), 0, s, ctx, wout, weff, C, bk, f16 ? 1 : 0,
+                     current_range_flag());
   return hipGetLastError();
 }
 

@@ -61,7 +61,8 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // i.e. 16/3 = 5.3x the fp32 MFMA rate; fp16 products are exact in the fp32 accumulator, so the error is the fp32 accumulation's
 // (measured: mean error of a K = 1,152 GEMM 3.40e-7 of mean|C| against 3.38e-7 for an fp32 sgemm).  The scaled lo plane is a
 // normal fp16 whenever hi is, so no operand scaling is needed for |x| in [6e-5, 65504]; smaller values lose nothing that matters
-// (absolute error floor 1.5e-11), larger ones are clamped by the producers.
+// (absolute error floor 1.5e-11); a larger one is never clamped: it turns into an infinity and sets the handle's range word
+// (kernels.h: split_f16x3 / range_report), which the caller answers by re-running on the exact-fp32 path.
 //
 // NWM = waves along M (2: 256 threads, 4: 512 threads = two waves per SIMD); NSTG = LDS operand buffers.  NSTG = 3 is the f16x3
 // GEMMs' pipeline: their 32-channel step is 24 MFMAs of 32 cycles per wave instead of 32 of 64, too short to cover the latency
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int NS = F16 ? 2 : BK / 8;    // F16: two 16-deep steps per 32-channel chunk
   constexpr int NP = F16 ? 2 : 1;         // fp16 planes per operand
   f32x4 fa0[MB * NP], fb0[2 * NP], fa1[MB * NP], fb1[2 * NP];
+  float amax = 0.f;                       // ASPLIT: largest magnitude this wave split (range report after the loop)
   auto load_frags = [&](f32x4* fa, f32x4* fb, const float* base, int s_) {
     if (F16) {
       // chunk (2 * kgroup + plane) of the row; lane half hh supplies channels 8 * (2 s + hh) .. + 7 of the chunk's 32
@@ -342,10 +344,10 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
           half8 hi, lo;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            // clamped to the fp16 range, as the pre-split producers do (one v_med3_f32 per value; measured 5 % of the level-0 3x3):
-            // an activation beyond 65504 becomes 65504 instead of an infinity that would poison every output it touches
-            const float x0 = __builtin_amdgcn_fmed3f(v0[k], -65504.f, 65504.f);
-            const float x1 = __builtin_amdgcn_fmed3f(v1[k], -65504.f, 65504.f);
+            // no clamp: a value beyond the fp16 range becomes an infinity (non-finite outputs, never a look-alike), a NaN stays one, and
+            // the running maximum (one v_max3_f32 per pair, abs modifiers free; a NaN never enters it) reports it once after the loop
+            const float x0 = v0[k], x1 = v1[k];
+            amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
             const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
             hi[k] = h0; hi[4 + k] = h1;
             lo[k] = (_Float16)((x0 - (float)h0) * 2048.f);
@@ -623,6 +625,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   if (WINO) fold(15);
 #endif
   }   // NSTG == 2
+  if (ASPLIT) range_report(a.range_flag, amax >= kF16Over, kRangeAct);
   if (!WINO) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -868,6 +871,7 @@ static int g_f16_tm = -1;      // US_F16_TM: rows per workgroup of the f16x3 GEM
 
 hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
+  a.range_flag = current_range_flag();
   if (a.B <= 0 || a.Hs <= 0 || a.Ws <= 0) return hipSuccess;
   if (!a.in || !a.wt || !a.out) return hipErrorInvalidValue;
   if ((a.bk != 16 && a.bk != 32) || a.Cin % a.bk != 0 || a.ntaps < 1 || a.ntaps > kMaxTaps) return hipErrorInvalidValue;
@@ -1008,7 +1012,8 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __
 // One thread = one 32-byte piece (8 input channels of one (tap, output channel)): two 16-byte stores.
 typedef _Float16 half8p __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void pack_conv_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin,
-                                                                   int KH, int KW, int oihw) {
+                                                                   int KH, int KW, int oihw, unsigned* range_flag) {
+  bool over = false;
   const long long total = (long long)KH * KW * Cout * (Cin / 8);
   const int nchunk = Cin / 32;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -1023,15 +1028,16 @@ __global__ __launch_bounds__(256) void pack_conv_weight_f16_kernel(const float* 
     for (int kk = 0; kk < 8; ++kk) {
       const int ci = ch * 32 + g4 * 8 + kk;
       const long long si = oihw ? (((long long)co * Cin + ci) * KH + ky) * KW + kx : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
-      const float c = fminf(fmaxf(src[si], -65504.f), 65504.f);
-      const _Float16 h = (_Float16)c;
+      us_half h, l;
+      split_f16x3(src[si], h, l, over);
       hi[kk] = h;
-      lo[kk] = (_Float16)fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+      lo[kk] = l;
     }
     _Float16* d = dst + i * 16;
     *reinterpret_cast<half8p*>(d) = hi;
     *reinterpret_cast<half8p*>(d + 8) = lo;
   }
+  range_report(range_flag, over, kRangeWeight);
 }
 
 hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s) {
@@ -1040,7 +1046,7 @@ hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, i
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_conv_weight_f16_kernel, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), Cout, Cin, KH, KW,
-                     oihw ? 1 : 0);
+                     oihw ? 1 : 0, current_range_flag());
   return hipGetLastError();
 }
 

@@ -110,9 +110,18 @@ struct us_decoder {
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
   bool presplit = true;      // US_PRESPLIT=0: block1's GroupNorm output stays fp32 for the direct block2 convolution (split in the kernel)
   bool xcd_z = true;         // US_XCD_Z=0: the Winograd-domain GEMMs dealt to the XCDs by tile only, not by whole frequencies (A/B)
+  bool wino_narrow = false; // US_WINO_NARROW=1: Winograd also for convolutions with cout <= dim below level 0 (add_resnet)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
                             // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
+  // f16x3 operand range (kernels.h): one device word that every split ORs into when it meets a value beyond the fp16 range, and a
+  // pinned host word us_range_status copies it to.  `exact`: the handle was created with US_CREATE_EXACT_FP32 (no f16x3 anywhere).
+  unsigned* range_flag = nullptr;
+  unsigned* range_host = nullptr;
+  bool exact = false;
+  // us_estimator_backward: {2^k, 2^-k} of the gradient entering the pass, and the table of everything it returns (scaled back in one launch)
+  float* grad_scale = nullptr;
+  CopyEnt* grad_tab_dev = nullptr;
   // RAW tensors (biases, GroupNorm affine, MLP weights: ~130 small ones) are copied by ONE table-driven launch per weight sync
   // instead of one hipMemcpyAsync each (fine-tuning re-loads every tensor after every optimiser step)
   std::vector<CopyEnt> pending_copies;
@@ -201,7 +210,11 @@ struct us_decoder {
     r.c2 = add_conv(p + ".block2.block.0", cout, cout, 3, true);
     r.g2 = add(p + ".block2.block.1.weight", {cout});
     r.b2 = add(p + ".block2.block.1.bias", {cout});
-    if (level >= wino_min_level) {
+    // Winograd F(2x2,3x3) from US_WINO_MIN_LEVEL down -- except where the output is as narrow as level 0 (cout <= dim: the last up
+    // level, 512 -> 128 and 128 -> 128 at 40 x T/2).  There the GEMMs have a single column tile, so nothing amortises the 4x-expanded V
+    // (503 MB written and read for the 512-channel input at B' = 3) and the direct form is faster: measured 341 -> ~260 us and
+    // 95 -> ~75 us per convolution, transform included (US_WINO_NARROW=1 brings the Winograd form back).
+    if (level >= wino_min_level && (cout > cfg.dim || wino_narrow)) {
       if (!r.first) r.c1.w->want_wino = true;
       r.c2.w->want_wino = true;
     }
@@ -862,9 +875,8 @@ inline hipError_t compute_time_block(EvalCtx& e, TimeBlock& tb, const float* coe
 
 #include "train_host.inc"
 
-int flush_copies(us_decoder* h, hipStream_t st) {
-  const size_t n = h->pending_copies.size();
-  if (n == 0) return US_OK;
+// ents[0..n) -> dev through the pinned staging ring (or a write-once table of its own while the stream is being captured)
+int upload_table(us_decoder* h, const CopyEnt* ents, size_t n, CopyEnt* dev, hipStream_t st) {
   if (n > h->copy_tab_cap) return h->fail(US_EINVAL, "internal: copy table overflow");
   const int slot = h->copy_tab_i++ & 3;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -873,17 +885,25 @@ int flush_copies(us_decoder* h, hipStream_t st) {
   if (cap != hipStreamCaptureStatusNone) {
     // a captured upload reads its host source at every replay: give it storage of its own that is never rewritten
     if (h->copy_tab_capture_used >= us_decoder::kCaptureTabs)
-      return h->fail(US_EINVAL, "more than %d weight syncs recorded into HIP graphs with this handle", us_decoder::kCaptureTabs);
+      return h->fail(US_EINVAL, "more than %d weight syncs / backward passes recorded into HIP graphs with this handle", us_decoder::kCaptureTabs);
     host = h->copy_tab_capture[h->copy_tab_capture_used++];
   } else if (h->copy_tab_ev[slot]) {
     (void)hipEventSynchronize(h->copy_tab_ev[slot]);      // the upload that last used this staging slot has completed
   }
-  memcpy(host, h->pending_copies.data(), n * sizeof(CopyEnt));
-  US_HIP(h, hipMemcpyAsync(h->copy_tab_dev, host, n * sizeof(CopyEnt), hipMemcpyHostToDevice, st));
+  memcpy(host, ents, n * sizeof(CopyEnt));
+  US_HIP(h, hipMemcpyAsync(dev, host, n * sizeof(CopyEnt), hipMemcpyHostToDevice, st));
   if (cap == hipStreamCaptureStatusNone) {
     if (!h->copy_tab_ev[slot]) US_HIP(h, hipEventCreateWithFlags(&h->copy_tab_ev[slot], hipEventDisableTiming));
     US_HIP(h, hipEventRecord(h->copy_tab_ev[slot], st));
   }
+  return US_OK;
+}
+
+int flush_copies(us_decoder* h, hipStream_t st) {
+  const size_t n = h->pending_copies.size();
+  if (n == 0) return US_OK;
+  int rc = upload_table(h, h->pending_copies.data(), n, h->copy_tab_dev, st);
+  if (rc) return rc;
   US_HIP(h, launch_copy_table(h->copy_tab_dev, (int)n, st));
   h->pending_copies.clear();
   return US_OK;
@@ -912,8 +932,11 @@ int check_shape(us_decoder* h, int Bp, int T) {
 // =======================================================================================================
 extern "C" {
 
-int us_decoder_create(us_handle* out, const us_config* cfg) {
+int us_decoder_create(us_handle* out, const us_config* cfg) { return us_decoder_create_ex(out, cfg, 0u); }
+
+int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   if (!out || !cfg) { g_last_error = "null argument"; return US_EINVAL; }
+  if (flags & ~(unsigned)US_CREATE_EXACT_FP32) { g_last_error = "unknown creation flag"; return US_EINVAL; }
   if (cfg->n_mults < 1 || cfg->n_mults > 6 || cfg->dim < 16 || cfg->dim % 16 != 0 || cfg->n_feats <= 0 || cfg->spk_emb_dim <= 0 ||
       cfg->spk_emb_dim % 4 != 0) {
     g_last_error = "unsupported configuration (dim must be a multiple of 16, 1 <= n_mults <= 6)";
@@ -933,6 +956,7 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   hipError_t e = conv_igemm_init();
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
+  if (const char* wl = getenv("US_WINO_NARROW")) h->wino_narrow = atoi(wl) != 0;
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS")) h->wino_fuse_min_wgs = atoll(wf);
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS_SMALL")) h->wino_fuse_min_wgs_small = atoll(wf);
   if (const char* wf = getenv("US_WINO_FUSE_SMALL_KN")) h->wino_fuse_small_kn = atoll(wf);
@@ -943,7 +967,16 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
   if (const char* wf = getenv("US_XCD_Z")) h->xcd_z = atoi(wf) != 0;
   if (const char* wf = getenv("US_PRESPLIT")) h->presplit = atoi(wf) != 0;
+  if (flags & US_CREATE_EXACT_FP32) h->f16x3 = false;
+  h->exact = !h->f16x3;
   h->build();
+  if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), 256) != hipSuccess || hipMemset(h->range_flag, 0, 256) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->range_host), 256) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&h->grad_scale), 256) != hipSuccess) {
+    g_last_error = "allocation of the range word failed";
+    return US_EHIP;
+  }
+  *h->range_host = 0u;
   {
     int max_cin = 2 * h->C.back();
     for (int c : h->C) if (2 * c > max_cin) max_cin = 2 * c;
@@ -988,8 +1021,9 @@ int us_decoder_create(us_handle* out, const us_config* cfg) {
       return US_EHIP;
     }
   }
-  h->copy_tab_cap = h->slots.size();
-  bool tab_ok = hipMalloc(reinterpret_cast<void**>(&h->copy_tab_dev), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
+  h->copy_tab_cap = h->slots.size() + 8;      // (+ the input gradients of a backward's table)
+  bool tab_ok = hipMalloc(reinterpret_cast<void**>(&h->copy_tab_dev), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void**>(&h->grad_tab_dev), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
   for (int i = 0; i < 4 && tab_ok; ++i)
     tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_host[i]), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
   for (int i = 0; i < us_decoder::kCaptureTabs && tab_ok; ++i)
@@ -1009,6 +1043,10 @@ int us_decoder_destroy(us_handle h) {
   for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   if (h->copy_tab_dev) (void)hipFree(h->copy_tab_dev);
+  if (h->grad_tab_dev) (void)hipFree(h->grad_tab_dev);
+  if (h->range_flag) (void)hipFree(h->range_flag);
+  if (h->range_host) (void)hipHostFree(h->range_host);
+  if (h->grad_scale) (void)hipFree(h->grad_scale);
   for (int i = 0; i < 4; ++i) { if (h->copy_tab_host[i]) (void)hipHostFree(h->copy_tab_host[i]); if (h->copy_tab_ev[i]) (void)hipEventDestroy(h->copy_tab_ev[i]); }
   for (int i = 0; i < us_decoder::kCaptureTabs; ++i) if (h->copy_tab_capture[i]) (void)hipHostFree(h->copy_tab_capture[i]);
   for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1038,6 +1076,7 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
   for (int i = 0; i < ndim; ++i)
     if (shape[i] != s->shape[i]) return h->fail(US_ESHAPE, "'%s': dim %d is %lld, expected %lld", key, i, (long long)shape[i], (long long)s->shape[i]);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  RangeScope range_scope(h->range_flag);      // the f16x3 packs report a weight beyond the fp16 range
   switch (s->kind) {
     case Kind::RAW:
       // deferred: one table-driven launch for all RAW tensors at the next us_decoder_flush_weights / computing entry point.  `data`
@@ -1109,7 +1148,26 @@ int us_estimator_forward(us_handle h, const float* x, const float* mask, const f
   Buffers b;
   plan(h, A, Bp, T, b);
   EvalCtx e{h, static_cast<hipStream_t>(stream), &b, Bp, T, mask, Bp};
+  RangeScope range_scope(h->range_flag);
   US_HIP(h, estimator_eval(e, x, Bp, mu, Bp, 0, t, spk, out, true));
+  return US_OK;
+}
+
+int us_range_status(us_handle h, unsigned* status, int reset, us_stream stream) {
+  if (!h || !status) { g_last_error = "null argument"; return US_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  US_HIP(h, hipMemcpyAsync(h->range_host, h->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (reset) US_HIP(h, hipMemsetAsync(h->range_flag, 0, sizeof(unsigned), st));
+  US_HIP(h, hipStreamSynchronize(st));
+  *status = *h->range_host;
+  return US_OK;
+}
+
+int us_range_status_async(us_handle h, unsigned* status_host, int reset, us_stream stream) {
+  if (!h || !status_host) { g_last_error = "null argument"; return US_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  US_HIP(h, hipMemcpyAsync(status_host, h->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (reset) US_HIP(h, hipMemsetAsync(h->range_flag, 0, sizeof(unsigned), st));
   return US_OK;
 }
 
@@ -1181,6 +1239,7 @@ int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const f
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int F = h->cfg.n_feats, S = h->cfg.spk_emb_dim;
   const size_t FT = (size_t)F * T;
+  RangeScope range_scope(h->range_flag);
 
   Arena A(workspace, workspace_bytes);
   float* xt = A.alloc<float>((size_t)mbs * FT);
@@ -1350,6 +1409,7 @@ int us_debug_block(us_handle h, int kind, const char* prefix, int level, const f
   Buffers b;
   plan(h, A, B, T, b);
   EvalCtx e{h, s, &b, B, T, mask, B};
+  RangeScope range_scope(h->range_flag);
   US_HIP(h, hipMemsetAsync(b.stats, 0, b.stats_count * sizeof(double), s));
   std::vector<const ResnetW*> rs;
   std::vector<const AttnW*> as;

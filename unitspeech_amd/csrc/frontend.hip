@@ -304,8 +304,6 @@ struct us_frontend {
   int device = 0;
   std::vector<std::string> keys;       // state_dict order
   std::map<std::string, us::Weight> w;
-  float* ws = nullptr;                 // activation scratch, grown on demand
-  size_t ws_floats = 0;
   std::string err;
 };
 
@@ -371,13 +369,17 @@ void duration_keys(us_frontend* h) {
   add_conv(h, "proj", 1, c.filter_channels, 1);
 }
 
-int fe_scratch(us_frontend* h, size_t floats) {
-  if (floats <= h->ws_floats) return US_OK;
-  if (h->ws) (void)hipFree(h->ws);
-  h->ws = nullptr; h->ws_floats = 0;
-  hipError_t e = hipMalloc(&h->ws, floats * sizeof(float));
-  if (e != hipSuccess) return fe_hip(h, "hipMalloc(front-end scratch)", e);
-  h->ws_floats = floats;
+// activation scratch of one forward call, in floats (the caller owns it: us_frontend_workspace_bytes)
+size_t fe_scratch_floats(const us_frontend* h, long long rows) {
+  if (h->kind == 0) return (size_t)rows * (6 * (size_t)h->ec.n_channels + (size_t)h->ec.filter_channels);      // x, x_org/y, q, k, v, a (C each) + h1 (F)
+  return (size_t)rows * ((size_t)(h->dc.in_channels + h->dc.spk_emb_dim) + 2 * (size_t)h->dc.filter_channels);
+}
+// the handle is bound to the device that was current at creation: weights live there, launches go to a stream of that device
+int fe_device(us_frontend* h, const char* what) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != h->device)
+    return fe_fail(h, US_EINVAL, std::string(what) + ": the current device (" + std::to_string(dev) + ") is not the handle's (" +
+                                     std::to_string(h->device) + ")");
   return US_OK;
 }
 
@@ -457,7 +459,6 @@ int us_frontend_destroy(us_frontend_handle h) {
     if (kv.second.dev) (void)hipFree(kv.second.dev);
     if (kv.second.packed) (void)hipFree(kv.second.packed);
   }
-  if (h->ws) (void)hipFree(h->ws);
   delete h;
   return US_OK;
 }
@@ -476,6 +477,8 @@ int us_frontend_load_weight(us_frontend_handle h, const char* key, const float* 
   bool same = ndim == (int)w.shape.size();
   for (int i = 0; same && i < ndim; ++i) same = shape[i] == w.shape[i];
   if (!same) return fe_fail(h, US_ESHAPE, std::string("us_frontend_load_weight: shape of '") + key + "' does not match the configuration");
+  int rcd = fe_device(h, "us_frontend_load_weight");
+  if (rcd != US_OK) return rcd;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t n = w.numel();
   hipError_t e;
@@ -491,8 +494,13 @@ int us_frontend_load_weight(us_frontend_handle h, const char* key, const float* 
   return US_OK;
 }
 
+size_t us_frontend_workspace_bytes(us_frontend_handle h, int B, int L) {
+  if (!h || B <= 0 || L <= 0) return 0;
+  return fe_scratch_floats(h, (long long)B * L) * sizeof(float) + 256;
+}
+
 int us_encoder_forward(us_frontend_handle h, const int64_t* ids, const int64_t* lengths, float* mu_x, float* x_out, float* x_mask, int B,
-                       int L, us_stream stream) {
+                       int L, void* workspace, size_t workspace_bytes, us_stream stream) {
   if (!h || h->kind != 0) return fe_fail(h, US_EINVAL, "us_encoder_forward: not an encoder handle");
   if (!ids || !lengths || !mu_x || !x_out || !x_mask || B <= 0 || L <= 0) return fe_fail(h, US_EINVAL, "us_encoder_forward: bad argument");
   if (B > 65535) return fe_fail(h, US_EINVAL, "us_encoder_forward: more than 65535 items");
@@ -503,10 +511,11 @@ int us_encoder_forward(us_frontend_handle h, const int64_t* ids, const int64_t* 
   const size_t attn_lds = ((size_t)L + D + 128) * sizeof(float);
   if (attn_lds > 64 * 1024) return fe_fail(h, US_EINVAL, "us_encoder_forward: more than ~16000 symbols per utterance");
   const long long rows = (long long)B * L;
-  // scratch: x, x_org/y, q, k, v, a (C each) + h1 (F)
-  if ((rc = fe_scratch(h, (size_t)rows * (6 * (size_t)C + F))) != US_OK) return rc;
+  if ((rc = fe_device(h, "us_encoder_forward")) != US_OK) return rc;
+  if (!workspace || workspace_bytes < us_frontend_workspace_bytes(h, B, L))
+    return fe_fail(h, US_EWORKSPACE, "us_encoder_forward: workspace too small (us_frontend_workspace_bytes)");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  float* x = h->ws;
+  float* x = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
   float* y = x + rows * C;
   float* q = y + rows * C;
   float* k = q + rows * C;
@@ -555,7 +564,7 @@ int us_encoder_forward(us_frontend_handle h, const int64_t* ids, const int64_t* 
 }
 
 int us_duration_predictor_forward(us_frontend_handle h, const float* x, const float* x_mask, const float* g, float* logw, int B, int L,
-                                  us_stream stream) {
+                                  void* workspace, size_t workspace_bytes, us_stream stream) {
   if (!h || h->kind != 1) return fe_fail(h, US_EINVAL, "us_duration_predictor_forward: not a duration-predictor handle");
   const auto& c = h->dc;
   if (!x || !x_mask || !logw || B <= 0 || L <= 0 || B > 65535) return fe_fail(h, US_EINVAL, "us_duration_predictor_forward: bad argument");
@@ -565,9 +574,11 @@ int us_duration_predictor_forward(us_frontend_handle h, const float* x, const fl
   if (rc != US_OK) return rc;
   const int Cin = c.in_channels + c.spk_emb_dim, F = c.filter_channels;
   const long long rows = (long long)B * L;
-  if ((rc = fe_scratch(h, (size_t)rows * ((size_t)Cin + 2 * (size_t)F))) != US_OK) return rc;
+  if ((rc = fe_device(h, "us_duration_predictor_forward")) != US_OK) return rc;
+  if (!workspace || workspace_bytes < us_frontend_workspace_bytes(h, B, L))
+    return fe_fail(h, US_EWORKSPACE, "us_duration_predictor_forward: workspace too small (us_frontend_workspace_bytes)");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  float* xin = h->ws;
+  float* xin = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
   float* a1 = xin + rows * Cin;
   float* a2 = a1 + rows * F;
   hipLaunchKernelGGL(fe_gather_concat_kernel, dim3(L, B), dim3(256), 0, s, x, g, xin, L, c.in_channels, c.spk_emb_dim);

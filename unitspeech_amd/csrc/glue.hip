@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256) void finetune_segment_kernel(const float* __re
     const int j = (int)(i % seg);
     const int f = (int)((i / seg) % F);
     const int b = (int)(i / ((long long)seg * F));
-    const bool live = j < count[b];
     const long long src = start[b] + j;
+    const bool live = j < count[b] && src >= 0 && src < Ly;      // (a window reaching past y reads zeros, never out of bounds)
     float yc = 0.f, cy = 0.f;
     if (live) {
       yc = y[((long long)b * F + f) * Ly + src];
@@ -298,6 +298,17 @@ hipError_t launch_first_conv_dgrad(const float* gy, const float* gr, const float
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(first_conv_dgrad_kernel, dim3((int)blocks), dim3(256), (size_t)20 * C * sizeof(float), s, gy, gr, w3, w1, mask, gmu, gx,
                      B, F, T, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_pow2_scale(const float* x, long long n, int target_log2, float* out2, hipStream_t s) {
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1024), 0, s, x, n, target_log2, out2);
+  return hipGetLastError();
+}
+
+hipError_t launch_scale(const float* x, const float* scalar_dev, float* out, long long n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(nblocks(n)), dim3(256), 0, s, x, scalar_dev, out, n);
   return hipGetLastError();
 }
 

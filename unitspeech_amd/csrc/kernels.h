@@ -26,6 +26,41 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
 }
 #endif
 
+// ---- f16x3 operand range ---------------------------------------------------------------------------------------------
+// An f16x3 GEMM operand is two fp16 planes, x ~= hi + lo * 2^-11 (hi = fp16(x), lo = fp16((x - hi) * 2^11)): exact to 22 bits for
+// |x| < 65520, the first magnitude fp16 rounds to infinity.  The reference computes in plain fp32 (unitspeech/unitspeech.py:46-96), so a
+// larger value must not be replaced quietly: every place that forms the two planes lets it become an infinity (the GEMM's outputs are
+// then non-finite, never a clamped look-alike), lets a NaN stay a NaN, and ORs a bit into the handle's range word, which
+// us_range_status reports and the Python mirror answers by re-running the call on the exact-fp32 MFMA path.
+constexpr float kF16Over = 65520.f;
+enum : unsigned {
+  kRangeAct = 1u,      // an activation (or Winograd-domain value, or gradient) beyond the fp16 range met an f16x3 split
+  kRangeWeight = 2u,   // a weight (or folded attention weight) did
+};
+#if defined(__HIPCC__)
+typedef _Float16 us_half;
+__device__ __forceinline__ void split_f16x3(float x, us_half& hi, us_half& lo, bool& over) {
+  const us_half h = (us_half)x;                 // +-inf beyond the range, NaN stays NaN
+  hi = h;
+  lo = (us_half)((x - (float)h) * 2048.f);      // |x - h| <= ulp(h) / 2 <= 16: the scaled remainder always fits
+  over |= fabsf(x) >= kF16Over;                 // false for a NaN: the reference would carry it too
+}
+__device__ __forceinline__ void range_report(unsigned* flag, bool over, unsigned bit) {
+  if (flag && over) atomicOr(flag, bit);        // rare by construction: no contention to speak of
+}
+#endif
+// The range word of the handle whose entry point is running on this host thread (decoder.hip sets it around every call that can
+// launch a split; null outside): launchers read it when they fill their kernel arguments.
+unsigned* current_range_flag();
+void set_range_flag(unsigned* p);
+struct RangeScope {        // RAII: the handle's range word is current while an entry point enqueues work
+  unsigned* prev;
+  explicit RangeScope(unsigned* p) : prev(current_range_flag()) { set_range_flag(p); }
+  ~RangeScope() { set_range_flag(prev); }
+  RangeScope(const RangeScope&) = delete;
+  RangeScope& operator=(const RangeScope&) = delete;
+};
+
 constexpr int kHeads = 4;       // unitspeech/unitspeech.py:79
 constexpr int kDimHead = 32;    // unitspeech/unitspeech.py:79
 constexpr int kHidden = kHeads * kDimHead;
@@ -70,6 +105,7 @@ struct ConvArgs {
                          // utterance's result never depends on what it is batched with (sampling)
   float* splitk_ws;      // optional scratch for split-K partial slabs (splitk_ws_floats floats); null disables split-K
   long long splitk_ws_floats;
+  unsigned* range_flag;  // set by the launcher (current_range_flag()): where an in-kernel f16x3 split reports an operand beyond the fp16 range
 #ifdef US_STAMP
   unsigned long long* stamp_out;   // diagnostic build only: per (workgroup, wave) {cycles at the vmcnt wait, at the barrier, in the body, steps}
 #endif
@@ -139,6 +175,7 @@ struct GnApplyArgs {
   const float* temb; int temb_ld;                          // optional [B][temb_ld] per-channel addend
   const float* res; int res_ld; int res_masked;            // optional residual (times mask when res_masked)
   int post_mask;
+  unsigned* range_flag;                                    // set by the launcher; out_split reports here
   int out_split;                                           // out receives the two-plane fp16 form (per 8 channels: 8 hi | 8 lo, same bytes
                                                            // as fp32) that a direct f16x3 convolution takes as a pre-split A operand;
                                                            // out must not alias y (a quad's lo plane lands on its neighbour's input)
@@ -178,6 +215,11 @@ hipError_t launch_fill(float* dst, float value, int n, hipStream_t s);
 // table-driven copy of many small fp32 tensors in one launch: tab[i] = {src, dst, n} in device memory
 struct CopyEnt { const float* src; float* dst; long long n; };
 hipError_t launch_copy_table(const CopyEnt* tab_dev, int n_entries, hipStream_t s);
+// dst[i] = src[i] * scale_dev[0] for every entry of the same kind of table (in place when src == dst)
+hipError_t launch_scale_table(const CopyEnt* tab_dev, int n_entries, const float* scale_dev, hipStream_t s);
+// out[0] = 2^k with max|x| * 2^k in [2^(target_log2 - 1), 2^target_log2), out[1] = 2^-k (1, 1 for an all-zero or non-finite x); glue.hip
+hipError_t launch_pow2_scale(const float* x, long long n, int target_log2, float* out2, hipStream_t s);
+hipError_t launch_scale(const float* x, const float* scalar_dev, float* out, long long n, hipStream_t s);
 // dst = src / ||src||_2 over n elements (spk_uncon normalisation, :358)
 hipError_t launch_l2_normalize(const float* src, float* dst, int n, hipStream_t s);
 
@@ -217,6 +259,9 @@ struct WgradArgs {
   int chunk;             // output pixels per workgroup (multiple of 8)
   int vchunk;            // f16x3 kernel, shared gw (gw_bstride == 0): pixels per workgroup of the range CONCATENATED over the B items
                          // (0 = per-item chunks as above); set by launch_wgrad
+  int exact;             // 1: the exact-fp32 MFMA form (a handle created with US_CREATE_EXACT_FP32), whatever US_WGRAD_F16 says
+  const float* gy_amax;  // device float: max |gy| over (at least) the pixels and channels this launch reads, taken by launch_wgrad_amax
+                         // into a zeroed word; the f16x3 form derives its exact power-of-two scale of the gradient operand from it
   int overwrite;         // 1: gw holds garbage; legal only when every element has exactly one writer (launch_wgrad_single_writer)
   unsigned long long dy_bits, dx_bits, wtap_bits;
   void set_tap(int i, int dy, int dx, int wtap) {
@@ -226,6 +271,8 @@ struct WgradArgs {
   }
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+// *out = max(*out, max |g[r][c]|) over rows x C (C, ld multiples of 4); *out must be zero (or an earlier maximum to extend)
+hipError_t launch_wgrad_amax(const float* g, int ld, long long rows, int C, float* out, hipStream_t s);
 // true when launch_wgrad(a) gives every gw element exactly one writing workgroup (LDS kernel, one pixel chunk per item, one item
 // or per-item gw): the caller may then skip zeroing gw and set a.overwrite
 bool launch_wgrad_single_writer(const WgradArgs& a);
@@ -287,6 +334,7 @@ struct WinoGnArgs {
   const double* stats;                 // [B][8][2] sums of y
   const float *gamma, *beta, *temb;    // temb: [B][C] or null
   const float* mask; int mask_ld, mask_step, mask_bmod;
+  unsigned* range_flag;                // set by the launcher
 };
 bool gn_wino_input_supported(int C);
 hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s, bool split = false);

@@ -8,6 +8,11 @@ namespace us {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// f16x3 range word of the handle whose entry point runs on this host thread (kernels.h)
+static thread_local unsigned* t_range_flag = nullptr;
+unsigned* current_range_flag() { return t_range_flag; }
+void set_range_flag(unsigned* p) { t_range_flag = p; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
   const long long stride = (long long)gridDim.x * 256;
   long long i = blockIdx.x * 256LL + threadIdx.x;
   const bool fixed_quad = (stride % C4) == 0;      // then (i % C4) never changes for this thread
+  bool over = false;
   int c = (int)(i % C4) * 4;
   f32x4 sc, sh, te = {0.f, 0.f, 0.f, 0.f};
   auto load_quad = [&](int cc) {
@@ -231,15 +237,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
     }
     if (a.post_mask) o *= m;
     if (a.out_split) {
-      // hi = fp16(x), lo = fp16((x - hi) * 2^11), clamped to the fp16 range as the Winograd input transforms do (wino.hip)
+      // hi = fp16(x), lo = fp16((x - hi) * 2^11); a value beyond the fp16 range is reported, not clamped (kernels.h)
       typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
       half4_t hi, lo;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float x = fminf(fmaxf(o[k], -65504.f), 65504.f);
-        const _Float16 h = (_Float16)x;
+        us_half h, l;
+        split_f16x3(o[k], h, l, over);
         hi[k] = h;
-        lo[k] = (_Float16)fminf(fmaxf((x - (float)h) * 2048.f, -65504.f), 65504.f);
+        lo[k] = l;
       }
       _Float16* oh = reinterpret_cast<_Float16*>(ob + p * a.out_ld) + 2 * (c & ~7) + (c & 7);
       *reinterpret_cast<half4_t*>(oh) = hi;
@@ -253,9 +259,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
       if (w >= a.W) w -= a.W;
     }
   }
+  if (a.out_split) range_report(a.range_flag, over, kRangeAct);
 }
 
-hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
+hipError_t launch_gn_apply(const GnApplyArgs& a_in, hipStream_t s) {
+  GnApplyArgs a = a_in;
+  a.range_flag = current_range_flag();
   if (a.C % 4 != 0 || a.C % kGroups != 0 || a.y_ld % 4 != 0 || a.out_ld % 4 != 0 || (a.res && a.res_ld % 4 != 0))
     return hipErrorInvalidValue;
   if (a.out_split && (a.C % 8 != 0 || a.out_ld % 8 != 0 || a.out == a.y)) return hipErrorInvalidValue;
@@ -389,6 +398,18 @@ hipError_t launch_copy_table(const CopyEnt* tab_dev, int n_entries, hipStream_t 
 __global__ void fill_kernel(float* __restrict__ dst, float value, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = value;
+}
+
+__global__ __launch_bounds__(256) void scale_table_kernel(const CopyEnt* __restrict__ tab, const float* __restrict__ scale) {
+  const CopyEnt e = tab[blockIdx.y];
+  const float k = scale[0];
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < e.n; i += (long long)gridDim.x * 256) e.dst[i] = e.src[i] * k;
+}
+
+hipError_t launch_scale_table(const CopyEnt* tab_dev, int n_entries, const float* scale_dev, hipStream_t s) {
+  if (n_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_table_kernel, dim3(64, n_entries), dim3(256), 0, s, tab_dev, scale_dev);
+  return hipGetLastError();
 }
 
 hipError_t launch_fill(float* dst, float value, int n, hipStream_t s) {

@@ -233,9 +233,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
 // ONCE into the fragment image (per channel 64 bytes: hi plane of the 16 pixels, lo plane; 16-byte chunks XOR-swizzled by
 // (channel >> 2) & 3 so that both the converting writes and the fragment reads spread over the banks) and every wave reads its
 // fragments from there with ds_read_b128: each value is split once per workgroup, not once per wave that uses it.
-// Gradients are small (a mean-reduced loss puts dL/dy around 1e-5, below fp16's normal range), so the workgroup first takes the
-// absolute maximum of (a sample of) ITS slice of gy and multiplies by the power of two that brings it to [2^10, 2^11): exact, undone
-// on the accumulators at the end.  hi = fp16(v), lo = fp16((v - hi) * 2^11); C = C_hh + 2^-11 C_x as in conv_igemm.hip.
+// The gradient operand is scaled by an exact, per-launch power of two (below).  hi = fp16(v), lo = fp16((v - hi) * 2^11);
+// C = C_hh + 2^-11 C_x as in conv_igemm.hip.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 constexpr int kWgKP16 = 16;
 
@@ -243,7 +242,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];      // raw: 2 stages x (A [16][128] + B [16][128]) fp32; then the fragment image
   constexpr int RAW = 2 * kWgKP16 * 128;                           // floats per raw stage (both operands)
   float* cimg = wsm + 2 * RAW;                                     // [2 operands][128 channels][16 floats = 64 bytes]
-  __shared__ float s_red[4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -274,28 +272,15 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_x =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.Hin * a.Win * a.x_ld), 0, (int)x_bytes, 0x00020000);
 
-  // ---- scale of the gradient operand: absolute maximum over this workgroup's pixels x 128 output channels
-  float mx = 0.f;
-  {
-    const int rl = tid >> 5, ch = (tid & 31) * 4;       // 8 pixel rows per pass, a channel quad per thread
-    // every eighth row of eight: the full slice was read nine times over by the tap workgroups (0.5 ms of a level-0 launch at 32 crops);
-    // the target below leaves 2^5 of headroom for what the sample misses (and the conversion saturates, it does not wrap)
-    for (int vm = m_lo + rl; vm < m_hi; vm += 64) {
-      const int bi = vm / Ms, m = vm - bi * Ms;        // (bi = 0 outside vmode)
-      const int yy = m / a.Ws, xx = m - yy * a.Ws;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(gy_b + (long long)bi * (gy_item / 4) +
-                                                      ((long long)(a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * a.gy_ld + co0 + ch);
-      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if (lane == 0) s_red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-  }
-  // 2^(10 - floor(log2 mx)), kept inside the normal range; an all-zero (or non-finite) slice is left unscaled
+  // ---- scale of the gradient operand.  Gradients are small (a mean-reduced loss puts dL/dy around 1e-5, below fp16's normal range), so
+  // gy is multiplied by the power of two that brings the largest magnitude of the WHOLE tensor (a.gy_amax, taken exactly by
+  // wgrad_amax_kernel just before this launch) to [2^14, 2^15): exact, undone on the accumulators at the end, and no scaled value can
+  // leave the fp16 range.  (Until round 3 every workgroup estimated the maximum of its own slice from a sample of its rows with 2^5 of
+  // headroom and clamped what the sample missed: a peaked gradient, e.g. behind the attention softmax, was saturated silently.)
+  const float mx = a.gy_amax ? *a.gy_amax : 0.f;
+  // 2^(14 - floor(log2 mx)), kept inside the normal range; an all-zero (or non-finite: it then propagates) tensor is left unscaled
   int e2 = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
-  int se = 10 - e2;
+  int se = 14 - e2;
   if (!(mx > 0.f) || e2 > 127) se = 0;
   se = se < -100 ? -100 : (se > 100 ? 100 : se);
   const float g_scale = __uint_as_float((unsigned)(127 + se) << 23), g_unscale = __uint_as_float((unsigned)(127 - se) << 23);
@@ -334,7 +319,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
       half8_t hi, lo;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float v = __builtin_amdgcn_fmed3f(src[k * 128] * sc, -65504.f, 65504.f);
+        // no clamp: the scaled gradient cannot leave the fp16 range (exact maximum above); an ACTIVATION beyond it becomes an infinity
+        // here as in the forward convolution that consumed the same tensor, which is where the range event was reported (kernels.h)
+        const float v = src[k * 128] * sc;
         const _Float16 h = (_Float16)v;
         hi[k] = h;
         lo[k] = (_Float16)((v - (float)h) * 2048.f);
@@ -407,6 +394,33 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
       }
 }
 
+// max |gy| over an [rows][C] window of a pixel-major tensor (ld floats per row), as float bits into *out (zeroed by the caller):
+// non-negative floats order like their bit patterns, so one atomicMax per wave does it; an infinity wins, a NaN is skipped (fmaxf).
+__global__ __launch_bounds__(256) void wgrad_amax_kernel(const float* __restrict__ g, int ld, long long rows, int C, unsigned* __restrict__ out) {
+  const int C4 = C >> 2;
+  const long long total = rows * C4;
+  float mx = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + r * ld + c);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __float_as_uint(mx));
+}
+
+hipError_t launch_wgrad_amax(const float* g, int ld, long long rows, int C, float* out, hipStream_t s) {
+  if (C % 4 != 0 || ld % 4 != 0) return hipErrorInvalidValue;
+  const long long total = rows * (C / 4);
+  long long blocks = (total + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(wgrad_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, ld, rows, C, reinterpret_cast<unsigned*>(out));
+  return hipGetLastError();
+}
+
 static bool wgrad_use_lds(const WgradArgs& a) {
   static int use_lds = -1;
   if (use_lds < 0) { const char* e = getenv("US_WGRAD_LDS"); use_lds = e ? atoi(e) : 1; }
@@ -435,7 +449,8 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     dim3 g2(a.B * ((Ms + a.chunk - 1) / a.chunk), (a.Cout / 128) * (a.Cin / 128), a.ntaps);
     static int use_f16 = -1;       // US_WGRAD_F16=0: the exact-fp32 MFMA form
     if (use_f16 < 0) { const char* e = getenv("US_WGRAD_F16"); use_f16 = e ? atoi(e) : 1; }
-    if (use_f16) {
+    if (use_f16 && !a.exact) {
+      if (!a.gy_amax) return hipErrorInvalidValue;      // the f16x3 form needs the exact maximum of gy (launch_wgrad_amax)
       WgradArgs a2 = a;
       static int target_wgs = -1;
       if (target_wgs < 0) { const char* e = getenv("US_WGRAD_WGS"); target_wgs = e ? atoi(e) : 1536; }

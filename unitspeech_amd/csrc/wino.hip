@@ -14,26 +14,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // SPLIT = true: every value is kept as two fp16 planes, v ~= hi + lo * 2^-11 with hi = fp16(v), lo = fp16((v - hi) * 2^11), interleaved
 // per group of 8 channels as [8 x hi][8 x lo] so that a pixel row keeps its fp32 byte length (C * 4).  `idx` is the fp32 element
 // index of a channel quad (c % 4 == 0): its hi quad sits at half index 2 * (idx - idx % 8) + idx % 8, its lo quad 8 halves further.
-// |v| is clamped to the fp16 range (65504); the GEMM's fp32 accumulation then carries the same error as an fp32 GEMM.
+// A Winograd-domain value beyond the fp16 range (|v| >= 65520; V = B^T d B reaches 4x the activation) is reported through `over`
+// (kernels.h: split_f16x3), never clamped; the GEMM's fp32 accumulation carries the same error as an fp32 GEMM.
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_f16(const f32x4& v, half4& hi, half4& lo) {
+__device__ __forceinline__ void split_f16(const f32x4& v, half4& hi, half4& lo, bool& over) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
-    const _Float16 h = (_Float16)c;
-    const float r = fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+    us_half h, l;
+    split_f16x3(v[k], h, l, over);
     hi[k] = h;
-    lo[k] = (_Float16)r;
+    lo[k] = l;
   }
 }
 template <bool SPLIT>
-__device__ __forceinline__ void store_v(float* __restrict__ V, long long idx, const f32x4& v) {
+__device__ __forceinline__ void store_v(float* __restrict__ V, long long idx, const f32x4& v, bool& over) {
   if (!SPLIT) {
     *reinterpret_cast<f32x4*>(V + idx) = v;
   } else {
     _Float16* vh = reinterpret_cast<_Float16*>(V);
     half4 hi, lo;
-    split_f16(v, hi, lo);
+    split_f16(v, hi, lo, over);
     const long long o = 2 * (idx & ~7LL) + (idx & 7);
     *reinterpret_cast<half4*>(vh + o) = hi;
     *reinterpret_cast<half4*>(vh + o + 8) = lo;
@@ -43,7 +43,8 @@ __device__ __forceinline__ void store_v(float* __restrict__ V, long long idx, co
 // one thread = one (tile, channel quad); grid (blocks, B)
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ V, int B, int H, int W,
-                                                         int C) {
+                                                         int C, unsigned* range_flag) {
+  bool over = false;
   const int C4 = C >> 2;
   const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
   const int b = blockIdx.y;
@@ -80,12 +81,13 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     for (int r = 0; r < 4; ++r) {
       // columns: v = t B
       f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1], v3 = tt[r][1] - tt[r][3];
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, v0);
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, v1);
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, v2);
-      store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, v3);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, v0, over);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, v1, over);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, v2, over);
+      store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, v3, over);
     }
   }
+  if (SPLIT) range_report(range_flag, over, kRangeAct);
 }
 
 hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s, bool split) {
@@ -94,8 +96,8 @@ hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, i
   int blocks = (int)((per_item + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  if (split) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C);
-  else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C);
+  if (split) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C, current_range_flag());
+  else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(blocks, B), dim3(256), 0, s, x, x_ld, V, B, H, W, C, (unsigned*)nullptr);
   return hipGetLastError();
 }
 
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restr
   const int tr = t / kGwTX, tc = t - tr * kGwTX;
   const int ty = ty0 + tr, tx = tx0 + tc;
   if (ty >= th || tx >= tw) return;
+  bool over = false;
   f32x4 d[4][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -178,11 +181,12 @@ __global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1], v3 = tt[r][1] - tt[r][3];
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, v0);
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, v1);
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, v2);
-    store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, v3);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 0) * plane, v0, over);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 1) * plane, v1, over);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 2) * plane, v2, over);
+    store_v<SPLIT>(V, vi + (long long)(r * 4 + 3) * plane, v3, over);
   }
+  if (SPLIT) range_report(g.range_flag, over, kRangeAct);
 }
 
 bool gn_wino_input_supported(int C) { return C % kGwCS == 0 && C % kGroups == 0; }
@@ -193,6 +197,7 @@ hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, i
   const int gy = ((th + kGwTY - 1) / kGwTY) * (C / kGwCS);
   if (gy > 65535 || B > 65535) return hipErrorInvalidValue;
   WinoGnArgs x = g;
+  x.range_flag = current_range_flag();
   if (x.mask_bmod < 1) x.mask_bmod = 1;
   if (split) hipLaunchKernelGGL(gn_wino_input_kernel<true>, dim3((tw + kGwTX - 1) / kGwTX, gy, B), dim3(256), 0, s, y, V, B, H, W, C, x);
   else hipLaunchKernelGGL(gn_wino_input_kernel<false>, dim3((tw + kGwTX - 1) / kGwTX, gy, B), dim3(256), 0, s, y, V, B, H, W, C, x);
@@ -283,7 +288,27 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       }
   }
   if (stats) {
-    flush();
+    // Final merge.  Every lane used to add its 8 fp64 partials to the 16 LDS words by atomics: 2,048 serialised updates per block
+    // (rocprofv3 had this kernel at 46 % LDS bank conflicts and 3.5 TB/s).  When a thread keeps its channel quad for life (grid stride a
+    // multiple of C/4: every power-of-two width) and the quads of a GroupNorm group are neighbouring lanes, the group's partials are
+    // first summed across those lanes by shuffles (fp64 sums: the order does not show at fp32 resolution) and one lane adds them.
+    const int seg = C4 / kGroups;          // lanes per group: 4 (C = 128) ... 32 (C = 1,024)
+    const bool wave_merge = (((long long)gridDim.x * 256) % C4) == 0 && seg >= 1 && seg <= 64 && (seg & (seg - 1)) == 0 && (64 % seg) == 0 &&
+                            (C4 % 64 == 0 || 64 % C4 == 0);
+    if (wave_merge) {
+      double s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]), s2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+      for (int off = 1; off < seg; off <<= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+      }
+      const int lane = threadIdx.x & 63;
+      if ((lane & (seg - 1)) == 0 && tc >= 0) {
+        atomicAdd(&s_g[tc / cg][0], s1);
+        atomicAdd(&s_g[tc / cg][1], s2);
+      }
+    } else {
+      flush();
+    }
     __syncthreads();
     if (threadIdx.x < kGroups * 2)
       stat_add(stats, b, threadIdx.x >> 1, threadIdx.x & 1, blockIdx.x, s_g[threadIdx.x >> 1][threadIdx.x & 1]);
@@ -344,7 +369,8 @@ __global__ void wino_pack_weight_kernel(const float* __restrict__ src, float* __
 // an iteration's 14 ms).
 typedef _Float16 half8w __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void wino_pack_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin,
-                                                                   int dgrad) {
+                                                                   int dgrad, unsigned* range_flag) {
+  bool over = false;
   const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
   const long long total = (long long)(K / 8) * N;          // thread = (k group of 8, n), k group fastest within a 32-channel row
   const long long fstride = (long long)K * N * 2;          // halves per frequency
@@ -375,10 +401,10 @@ __global__ __launch_bounds__(256) void wino_pack_weight_f16_kernel(const float* 
         const float u[4] = {gg[r][0], 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]), 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]), gg[r][2]};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float c = fminf(fmaxf(u[q], -65504.f), 65504.f);
-          const _Float16 h = (_Float16)c;
+          us_half h, l;
+          split_f16x3(u[q], h, l, over);
           hi[r * 4 + q][kk] = h;
-          lo[r * 4 + q][kk] = (_Float16)fminf(fmaxf((c - (float)h) * 2048.f, -65504.f), 65504.f);
+          lo[r * 4 + q][kk] = l;
         }
       }
     }
@@ -389,6 +415,7 @@ __global__ __launch_bounds__(256) void wino_pack_weight_f16_kernel(const float* 
       *reinterpret_cast<half8w*>(d + f * fstride + 8) = lo[f];
     }
   }
+  range_report(range_flag, over, kRangeWeight);
 }
 
 hipError_t launch_wino_pack_weight_f16(const float* src, float* dst, int Cout, int Cin, hipStream_t s, bool dgrad) {
@@ -396,7 +423,8 @@ hipError_t launch_wino_pack_weight_f16(const float* src, float* dst, int Cout, i
   long long total = (long long)Cout * Cin / 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wino_pack_weight_f16_kernel, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), Cout, Cin, dgrad ? 1 : 0);
+  hipLaunchKernelGGL(wino_pack_weight_f16_kernel, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), Cout, Cin, dgrad ? 1 : 0,
+                     current_range_flag());
   return hipGetLastError();
 }
 

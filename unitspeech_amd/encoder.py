@@ -208,19 +208,30 @@ class _FrontEndModule(torch.nn.Module):
                 self._create(lib, device)
             self._device, self._versions = device, {}
         stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        for key, t in self.state_dict(keep_vars=True).items():
-            tag = (t.data_ptr(), t._version, t.device)
-            if self._versions.get(key) == tag:
-                continue
-            in_place = t.dtype == torch.float32 and t.device == device and t.is_contiguous()
-            src = t.detach() if in_place else t.detach().to(device=device, dtype=torch.float32).contiguous()
-            shape = (C.c_int64 * src.dim())(*src.shape)
-            rc = lib.us_frontend_load_weight(self._h, key.encode(), src.data_ptr(), shape, src.dim(), stream)
-            self._check(lib, rc, f"us_frontend_load_weight({key})")
-            if not in_place:
-                torch.cuda.current_stream(device).synchronize()      # the temporary must outlive the copy
-            self._versions[key] = tag
+        # the handle allocates its weight store on the CURRENT device and refuses calls made under another one (frontend.hip: fe_device)
+        with torch.cuda.device(device):
+            for key, t in self.state_dict(keep_vars=True).items():
+                tag = (t.data_ptr(), t._version, t.device)
+                if self._versions.get(key) == tag:
+                    continue
+                in_place = t.dtype == torch.float32 and t.device == device and t.is_contiguous()
+                src = t.detach() if in_place else t.detach().to(device=device, dtype=torch.float32).contiguous()
+                shape = (C.c_int64 * src.dim())(*src.shape)
+                rc = lib.us_frontend_load_weight(self._h, key.encode(), src.data_ptr(), shape, src.dim(), stream)
+                self._check(lib, rc, f"us_frontend_load_weight({key})")
+                if not in_place:
+                    torch.cuda.current_stream(device).synchronize()      # the temporary must outlive the copy
+                self._versions[key] = tag
         return lib, stream
+
+    def _workspace(self, lib, device, B, L):
+        """Caller-owned activation scratch of one forward call (torch's caching allocator: no hipMalloc / hipFree in the call)."""
+        n = int(lib.us_frontend_workspace_bytes(self._h, B, L))
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < n or ws.device != device:
+            self._ws = None
+            self._ws = ws = torch.empty(n, dtype=torch.uint8, device=device)
+        return ws
 
     def _check(self, lib, rc, what):
         if rc != _lib.US_OK:
@@ -276,7 +287,10 @@ class Encoder(_FrontEndModule):
         mu_x = torch.empty(b, self.cfg.n_feats, l, device=device)
         h = torch.empty(b, self.cfg.n_channels, l, device=device)
         mask = torch.empty(b, 1, l, device=device)
-        rc = lib.us_encoder_forward(self._h, ids.data_ptr(), lens.data_ptr(), mu_x.data_ptr(), h.data_ptr(), mask.data_ptr(), b, l, stream)
+        ws = self._workspace(lib, device, b, l)
+        with torch.cuda.device(device):
+            rc = lib.us_encoder_forward(self._h, ids.data_ptr(), lens.data_ptr(), mu_x.data_ptr(), h.data_ptr(), mask.data_ptr(), b, l,
+                                        ws.data_ptr(), ws.numel(), stream)
         self._check(lib, rc, "us_encoder_forward")
         return mu_x, h, mask
 
@@ -316,7 +330,9 @@ class DurationPredictor(_FrontEndModule):
         xs, ms = f32(x), f32(x_mask)
         gs = f32(g) if g is not None else None
         logw = torch.empty(x.shape[0], 1, x.shape[2], device=device)
-        rc = lib.us_duration_predictor_forward(self._h, xs.data_ptr(), ms.data_ptr(), gs.data_ptr() if gs is not None else None,
-                                               logw.data_ptr(), x.shape[0], x.shape[2], stream)
+        ws = self._workspace(lib, device, x.shape[0], x.shape[2])
+        with torch.cuda.device(device):
+            rc = lib.us_duration_predictor_forward(self._h, xs.data_ptr(), ms.data_ptr(), gs.data_ptr() if gs is not None else None,
+                                                   logw.data_ptr(), x.shape[0], x.shape[2], ws.data_ptr(), ws.numel(), stream)
         self._check(lib, rc, "us_duration_predictor_forward")
         return logw

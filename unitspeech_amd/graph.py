@@ -52,13 +52,30 @@ class FineTuneGraph:
             p.grad = None
         decoder.invalidate_weights()                       # the captured graph re-packs EVERY weight: parameters change every replay
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the warm-up stream: the AccumulateGrad nodes created there stay bound to it, and a capture on another stream would
+        # only work through autograd's cross-stream waits happening to be captured too
+        with torch.cuda.graph(self.graph, stream=side):
             loss, _ = decoder.compute_loss(self.y, self.mask, self.cond, spk_emb=self.spk)
             loss.backward()
         self.loss = loss.detach()
+        # the graph holds raw pointers: parameter and gradient storage, the engine's packed weights and staging tables
+        self._engine = decoder._get_engine()
+        self._handle = self._engine.handle.value
+        self._ptrs = [(p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0) for p in self.params]
+
+    def _check_alive(self):
+        eng = self.decoder._get_engine()
+        if eng is not self._engine or eng.handle.value != self._handle:
+            raise RuntimeError("FineTuneGraph: the decoder's engine was re-created (device move, `exact` switched) after capture; "
+                               "build a new FineTuneGraph")
+        for p, (dp, gp) in zip(self.params, self._ptrs):
+            if p.data_ptr() != dp or (p.grad is not None and p.grad.data_ptr() != gp) or (p.grad is None and gp != 0):
+                raise RuntimeError("FineTuneGraph: parameter or gradient storage changed after capture (decoder.to(), "
+                                   "load_state_dict(assign=True), zero_grad(set_to_none=True), ...); build a new FineTuneGraph")
 
     def step(self, cond_x, y, y_lengths, attn) -> torch.Tensor:
         """One `fine_tune` call plus `loss.backward()`: gradients land in `p.grad` (static tensors), returns the loss (static)."""
+        self._check_alive()
         self.decoder.fine_tune_segment(cond_x, y, y_lengths, attn, self.segment_size, self.n_feats, out=(self.y, self.mask, self.cond))
         self.graph.replay()
         return self.loss

@@ -41,16 +41,31 @@ def unpack_state_dict(cfg: DecoderConfig, flat: torch.Tensor) -> "OrderedDict[st
     return out
 
 
-def broadcast_state_dict(cfg: DecoderConfig, sd_on_rank0, rank: int, world: int, device) -> "OrderedDict[str, torch.Tensor]":
-    """Rank 0 holds `sd_on_rank0`; every rank returns views into its copy of the packed blob."""
+def broadcast_state_dict(cfg: DecoderConfig, sd_on_rank0, rank: int, world: int, device, timing: dict = None) -> "OrderedDict[str, torch.Tensor]":
+    """Rank 0 holds `sd_on_rank0`; every rank returns views into its copy of the packed blob.  `timing` (optional dict) receives
+    `broadcast_ms` -- the collective alone, between device synchronisations, slowest rank's view after the caller's max-reduce is
+    not needed: the broadcast ends everywhere within one ring pass -- and `bytes`."""
+    import time
     total = sum(int(np.prod(s)) for s in param_shapes(cfg).values())
     if rank == 0:
         flat = pack_state_dict(cfg, sd_on_rank0, device)
     else:
         flat = torch.empty(total, dtype=torch.float32, device=device)
+    if timing is not None:
+        timing["bytes"] = int(total) * 4
+        timing["broadcast_ms"] = None
     if world > 1:
         import torch.distributed as dist
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
         dist.broadcast(flat, src=0)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        if timing is not None:
+            timing["broadcast_ms"] = 1e3 * (time.perf_counter() - t0)
     return unpack_state_dict(cfg, flat)
 
 

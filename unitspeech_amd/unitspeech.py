@@ -11,7 +11,9 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import random
+import warnings
 from typing import Optional, Sequence
 
 import torch
@@ -115,21 +117,26 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
-def _scale_gradient(n_elements: int) -> bool:
-    """Whether the gradient entering `us_estimator_backward` is brought into fp16's normal range by a power of two first (and the
-    results divided by it): beyond 2^14 elements under the loss's mean, i.e. more than one 176-frame crop, where the unscaled backward
-    starts to lose precision (one crop measures 4.7e-7 against the exact-fp32 backward without it and skips the two extra passes).
-    UNITSPEECH_GRAD_SCALE=0/1 forces it off / on."""
-    import os
-    e = os.environ.get("UNITSPEECH_GRAD_SCALE")
-    return bool(int(e)) if e is not None else n_elements > (1 << 14)
+class RangeError(RuntimeError):
+    """A tensor beyond the fp16 range (|x| >= 65520) met an f16x3 GEMM of the default engine in a call that cannot be repeated
+    transparently (training): the affected results are non-finite, not clamped.  Set ``UNITSPEECH_EXACT=1`` (or
+    ``model.exact = True``) to run every GEMM on the exact-fp32 matrix instruction."""
+
+
+def _exact_default() -> bool:
+    return os.environ.get("UNITSPEECH_EXACT", "0") not in ("", "0")
 
 
 class _Engine:
-    """Owns one `us_handle`, its weight synchronisation state and the scratch workspace."""
+    """Owns one `us_handle`, its weight synchronisation state and the scratch workspace.  exact=True: the handle is created with
+    US_CREATE_EXACT_FP32 (fp32 MFMA everywhere; the fall-back for tensors beyond the fp16 range, include/unitspeech_hip.h)."""
 
-    def __init__(self, n_feats, dim, dim_mults, beta_min, beta_max, pe_scale, spk_emb_dim):
+    def __init__(self, n_feats, dim, dim_mults, beta_min, beta_max, pe_scale, spk_emb_dim, exact=False):
         self.lib = _lib.load()
+        self.exact = bool(exact)
+        self.weights_out_of_range = False     # a weight beyond the fp16 range was packed (sticky until the weights change)
+        self._range_host = None               # pinned int32 the asynchronous status lands in (training: checked one call late)
+        self._range_event = None
         cfg = _lib.us_config()
         cfg.n_feats, cfg.dim, cfg.n_mults = int(n_feats), int(dim), len(dim_mults)
         for i, m in enumerate(dim_mults):
@@ -151,9 +158,13 @@ class _Engine:
             return
         self.close()
         with torch.cuda.device(device):
-            _lib.check(self.lib.us_decoder_create(C.byref(self.handle), C.byref(self.cfg)), None, "us_decoder_create")
+            flags = _lib.US_CREATE_EXACT_FP32 if self.exact else 0
+            _lib.check(self.lib.us_decoder_create_ex(C.byref(self.handle), C.byref(self.cfg), flags), None, "us_decoder_create_ex")
         self.device = device
         self.versions = {}
+        self.weights_out_of_range = False
+        self._range_host = None
+        self._range_event = None
 
     def close(self):
         if self.handle:
@@ -192,6 +203,7 @@ class _Engine:
                 keep.append(src)
             if keep:
                 _lib.check(self.lib.us_decoder_flush_weights(self.handle, stream), self.handle, "us_decoder_flush_weights")
+                self.weights_out_of_range = False     # re-packed: the next status read says whether they fit now
             del keep      # stream-ordered: the caching allocator keeps freed blocks intact for work already queued on this stream
 
     def invalidate(self, keys=None):
@@ -202,6 +214,41 @@ class _Engine:
         else:
             for k in keys:
                 self.versions.pop(k, None)
+
+    # -- f16x3 operand range (include/unitspeech_hip.h: us_range_status) -------------------------------------------------
+    def range_status(self, reset: bool = True) -> int:
+        """Blocking read of the handle's range word (waits for the current stream): 0 = everything since the last reset is
+        fp32-accurate; bit 1 = an activation / gradient, bit 2 = a weight beyond the fp16 range met an f16x3 split."""
+        if self.exact or not self.handle:
+            return 0
+        st = C.c_uint(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.us_range_status(self.handle, C.byref(st), 1 if reset else 0, _stream()), self.handle, "us_range_status")
+        if st.value & _lib.US_RANGE_WEIGHT:
+            self.weights_out_of_range = True
+        return int(st.value)
+
+    def range_post(self):
+        """Training: enqueue an asynchronous copy of the range word (no host wait); `range_poll` looks at it one call later."""
+        if self.exact or not self.handle:
+            return
+        with torch.cuda.device(self.device):
+            if self._range_host is None:
+                self._range_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._range_event = torch.cuda.Event()
+            _lib.check(self.lib.us_range_status_async(self.handle, C.c_void_p(self._range_host.data_ptr()), 0, _stream()), self.handle,
+                       "us_range_status_async")
+            self._range_event.record(torch.cuda.current_stream())
+
+    def range_poll(self):
+        """Raise RangeError when an earlier training call on this engine reported a tensor beyond the fp16 range."""
+        if self.exact or self._range_event is None or not self._range_event.query():
+            return
+        st = int(self._range_host.item())
+        if st:
+            self.range_status(reset=True)
+            raise RangeError(f"f16x3 range status {st}: a tensor beyond +-65504 reached a split-precision GEMM of a training call; "
+                             "its results are non-finite.  Re-run with UNITSPEECH_EXACT=1 (model.exact = True)")
 
     def get_workspace(self, nbytes: int, device) -> torch.Tensor:
         if self.workspace is None or self.workspace.numel() < nbytes or self.workspace.device != device:
@@ -234,6 +281,8 @@ class _EstimatorFn(torch.autograd.Function):
     def forward(ctx, est, eng, x, mask, mu, t, spk, keys, *params):
         B, F, T = x.shape
         dev = x.device
+        if not torch.cuda.is_current_stream_capturing():
+            eng.range_poll()                    # an overflow reported by the previous iteration's calls
         out = torch.empty_like(x)
         tape = C.c_uint64(0)
         with torch.cuda.device(dev):
@@ -255,19 +304,8 @@ class _EstimatorFn(torch.autograd.Function):
         eng, keys, dev = ctx.eng, ctx.keys, ctx.dev
         B, F, T = ctx.shape
         g = _f32c(grad_out, dev)
-        # The backward GEMMs take their operands as two fp16 planes (f16x3); a mean-reduced loss puts dL/dscore around
-        # 1 / (B * F * T), which at pre-training batches is below fp16's normal range (6e-5) and would leave the hi plane a handful
-        # of bits.  Scale the incoming gradient by a power of two (exact) that brings it back to the range it has at B = 1 and undo
-        # it on everything the backward returns: loss scaling with an exact inverse.
-        # The factor comes from the data (largest |g| to [2^-7, 2^-6)), so a summed loss or a caller's own loss scaling is as safe as a mean.
-        scaled = _scale_gradient(B * F * T)
-        if scaled:
-            sc = torch.empty(2, dtype=torch.float32, device=dev)          # {2^k, 2^-k}
-            gs = torch.empty_like(g)
-            with torch.cuda.device(dev):
-                _lib.check(eng.lib.us_pow2_scale(_dev_ptr(g), g.numel(), -6, _dev_ptr(sc), _stream()), None, "us_pow2_scale")
-                _lib.check(eng.lib.us_scale(_dev_ptr(g), _dev_ptr(sc), _dev_ptr(gs), g.numel(), _stream()), None, "us_scale")
-            g = gs
+        # (the library scales g by an exact, data-driven power of two for its split-precision GEMMs and scales everything it returns
+        # back: include/unitspeech_hip.h, us_estimator_backward)
         # one zero-filled blob, one view per parameter: a single fill instead of one per tensor
         sizes = [int(torch.Size(shape).numel()) for shape, _ in ctx.param_meta]
         offs, total = [], 0
@@ -289,12 +327,8 @@ class _EstimatorFn(torch.autograd.Function):
                                                opt(gx), opt(gmu), opt(gspk), _stream())
         ctx.tape.live = False                   # consumed (or refused) by the library either way
         _lib.check(rc, eng.handle, "us_estimator_backward")
-        if scaled:
-            inv = sc[1:]
-            with torch.cuda.device(dev):
-                for t in (blob, gx, gmu, gspk):
-                    if t is not None:
-                        _lib.check(eng.lib.us_scale(_dev_ptr(t), _dev_ptr(inv), _dev_ptr(t), t.numel(), _stream()), None, "us_scale")
+        if not torch.cuda.is_current_stream_capturing():
+            eng.range_post()
         ctx.ws = None
         ctx.inputs = None
         eng.last_grad_blob = blob               # data-parallel training all-reduces this one buffer (sharding.allreduce_gradients)
@@ -380,6 +414,21 @@ class _DiffusionLossFn(torch.autograd.Function):
         return None, out, None, None, None, None, None
 
 
+def _run_checked(eng, run, exact_engine, range_check, what):
+    """Inference calls: run on `eng`; when its f16x3 GEMMs met a tensor beyond the fp16 range (the results are then non-finite where it
+    mattered, never clamped), repeat the call on the exact-fp32 engine, as the reference's plain fp32 arithmetic would have carried
+    the value (unitspeech/unitspeech.py:46-96).  The status read waits for the stream; `range_check=False` skips it."""
+    out = run(eng)
+    if eng.exact or not range_check or torch.cuda.is_current_stream_capturing():
+        return out
+    st = eng.range_status(reset=True)
+    if st:
+        warnings.warn(f"{what}: a tensor beyond the fp16 range reached a split-precision GEMM (range status {st}); "
+                      "repeating the call on the exact-fp32 engine", RuntimeWarning, stacklevel=3)
+        out = run(exact_engine())
+    return out
+
+
 def _check_shapes(B, F, T, S, **tensors):
     """Raise before the C ABI sees a pointer whose extent does not match (it takes raw device pointers and never broadcasts)."""
     want = {"x": (B, F, T), "z": (B, F, T), "mu": (B, F, T), "cond": (B, F, T), "mask": (B, 1, T), "spk_emb": (B, 1, S), "t": (B,)}
@@ -430,17 +479,26 @@ class GradLogPEstimator2d(BaseModule):
                 Upsample(d_in)]))
         self.final_block = Block(dim, dim)
         self.final_conv = torch.nn.Conv2d(dim, 1, 1)
-        # engine used when the estimator is called on its own (a parent UnitSpeech shares its engine instead)
-        self._engine: Optional[_Engine] = None
+        # engines used when the estimator is called on its own (a parent UnitSpeech shares its engines instead): the default one
+        # (f16x3 GEMMs) and, created on first need, the exact-fp32 one that takes over for tensors beyond the fp16 range
+        self._engines = {}
         self._owner = None
+        self.exact = _exact_default()       # True: every call on the exact-fp32 engine (UNITSPEECH_EXACT=1)
+        self.range_check = True             # False: inference calls skip the (blocking) range-status read after each call
 
     # -- engine plumbing ---------------------------------------------------------------------------
-    def _get_engine(self, n_feats: int) -> _Engine:
+    def _get_engine(self, n_feats: int, exact: bool = False) -> _Engine:
         if self._owner is not None:
-            return self._owner._get_engine()
-        if self._engine is None or self._engine.cfg.n_feats != n_feats:
-            self._engine = _Engine(n_feats, self.dim, self.dim_mults, 0.05, 20.0, self.pe_scale, self.spk_emb_dim)
-        return self._engine
+            return self._owner._get_engine(exact)
+        eng = self._engines.get(bool(exact))
+        if eng is None or eng.cfg.n_feats != n_feats:
+            eng = _Engine(n_feats, self.dim, self.dim_mults, 0.05, 20.0, self.pe_scale, self.spk_emb_dim, exact=exact)
+            self._engines[bool(exact)] = eng
+        return eng
+
+    def _flags(self):
+        o = self._owner if self._owner is not None else self
+        return bool(o.exact), bool(o.range_check)
 
     def _named_weights(self, prefix="estimator."):
         for k, v in self.state_dict(keep_vars=True).items():
@@ -457,14 +515,23 @@ class GradLogPEstimator2d(BaseModule):
         if self._owner is not None and F != self._owner.n_feats:
             raise ValueError(f"x has {F} mel bins, the decoder was built for n_feats={self._owner.n_feats}")
         _check_shapes(B, F, T, self.spk_emb_dim, mu=mu, mask=mask, spk_emb=spk_emb, t=t)
-        eng = self._get_engine(F)
         weights = list(self._named_weights())
         if self._owner is None:
             z = lambda *s: torch.zeros(*s, device=dev)
             weights += [("text_uncon", z(1, F, 1)), ("spk_uncon", z(1, 1, self.spk_emb_dim))]
         else:
             weights += self._owner._own_weights()
-        eng.sync_weights(weights, dev)
+        want_exact, range_check = self._flags()
+
+        def engine(exact):
+            e = self._get_engine(F, exact)
+            e.sync_weights(weights, dev)
+            if not e.exact and e.weights_out_of_range:      # a weight beyond the fp16 range: the default engine cannot hold this set
+                e = self._get_engine(F, True)
+                e.sync_weights(weights, dev)
+            return e
+
+        eng = engine(want_exact)
         x, mu, mask, t, spk = (_f32c(v, dev) for v in (x, mu, mask, t, spk_emb))
         wants_grad = any(p.requires_grad for p in self.parameters()) or any(v.requires_grad for v in (x, mu, spk))
         if torch.is_grad_enabled() and wants_grad:
@@ -472,14 +539,18 @@ class GradLogPEstimator2d(BaseModule):
             # spk_emb (a frozen decoder still passes d loss / d mu on to the caller's encoder, train_STEP2.py:130-131,299)
             named = list(self._named_weights())
             return _EstimatorFn.apply(self, eng, x, mask.detach(), mu, t.detach(), spk, [k for k, _ in named], *[p for _, p in named])
-        out = torch.empty_like(x)
-        with torch.cuda.device(dev):
-            nbytes = eng.lib.us_workspace_bytes(eng.handle, B, T)
-            ws = eng.get_workspace(nbytes, dev)
-            rc = eng.lib.us_estimator_forward(eng.handle, _dev_ptr(x), _dev_ptr(mask), _dev_ptr(mu), _dev_ptr(t), _dev_ptr(spk),
-                                              _dev_ptr(out), B, T, _dev_ptr(ws), ws.numel(), _stream())
-        _lib.check(rc, eng.handle, "us_estimator_forward")
-        return out
+
+        def run(e):
+            out = torch.empty_like(x)
+            with torch.cuda.device(dev):
+                nbytes = e.lib.us_workspace_bytes(e.handle, B, T)
+                ws = e.get_workspace(nbytes, dev)
+                rc = e.lib.us_estimator_forward(e.handle, _dev_ptr(x), _dev_ptr(mask), _dev_ptr(mu), _dev_ptr(t), _dev_ptr(spk),
+                                                _dev_ptr(out), B, T, _dev_ptr(ws), ws.numel(), _stream())
+            _lib.check(rc, e.handle, "us_estimator_forward")
+            return out
+
+        return _run_checked(eng, run, lambda: engine(True), range_check, "GradLogPEstimator2d.forward")
 
 
 def get_noise(t, beta_init, beta_term, cumulative=False):
@@ -508,15 +579,24 @@ class UnitSpeech(BaseModule):
         self.estimator = GradLogPEstimator2d(dim, dim_mults=dim_mults, pe_scale=pe_scale, spk_emb_dim=spk_emb_dim,
                                              n_feats=n_feats)
         object.__setattr__(self.estimator, "_owner", self)     # not a sub-module: avoid a reference cycle in state_dict
-        self._engine_obj: Optional[_Engine] = None
+        self._engine_objs = {}        # exact? -> _Engine (the exact-fp32 one is created on first need)
         self.micro_batch = 0          # 0 = library default
+        self.exact = _exact_default()       # True: every call on the exact-fp32 engine (UNITSPEECH_EXACT=1)
+        self.range_check = True             # False: sampling calls skip the (blocking) range-status read after each call
 
     # -- engine plumbing ---------------------------------------------------------------------------
-    def _get_engine(self) -> _Engine:
-        if self._engine_obj is None:
-            self._engine_obj = _Engine(self.n_feats, self.dim, self.dim_mults, self.beta_min, self.beta_max, self.pe_scale,
-                                       self.spk_uncon.shape[-1])
-        return self._engine_obj
+    def _get_engine(self, exact: Optional[bool] = None) -> _Engine:
+        exact = bool(self.exact) if exact is None else bool(exact)
+        eng = self._engine_objs.get(bool(exact))
+        if eng is None:
+            eng = _Engine(self.n_feats, self.dim, self.dim_mults, self.beta_min, self.beta_max, self.pe_scale,
+                          self.spk_uncon.shape[-1], exact=exact)
+            self._engine_objs[bool(exact)] = eng
+        return eng
+
+    @property
+    def _engine_obj(self):
+        return self._engine_objs.get(False)
 
     def _own_weights(self):
         return [("text_uncon", self.text_uncon), ("spk_uncon", self.spk_uncon)]
@@ -525,13 +605,22 @@ class UnitSpeech(BaseModule):
         """Tell the engine that parameter storage was written in place behind autograd's back (`p.data.copy_()`, `p.data.mul_()`,
         EMA / clamp idioms do not bump `p._version`, which is what the upload cache is keyed on): the next call re-uploads
         everything (or the given state_dict keys)."""
-        if self._engine_obj is not None:
-            self._engine_obj.invalidate(keys)
+        for eng in self._engine_objs.values():
+            eng.invalidate(keys)
 
-    def _sync(self, device):
-        eng = self._get_engine()
-        eng.sync_weights(list(self.estimator._named_weights()) + self._own_weights(), device)
+    def _sync(self, device, exact: bool = False):
+        weights = list(self.estimator._named_weights()) + self._own_weights()
+        eng = self._get_engine(exact or self.exact)
+        eng.sync_weights(weights, device)
+        if not eng.exact and eng.weights_out_of_range:      # a weight beyond the fp16 range: only the exact engine can hold this set
+            eng = self._get_engine(True)
+            eng.sync_weights(weights, device)
         return eng
+
+    def range_status(self, reset: bool = True) -> int:
+        """Blocking read of the default engine's f16x3 range word (0 = clean; see include/unitspeech_hip.h: us_range_status)."""
+        eng = self._engine_objs.get(False)
+        return eng.range_status(reset) if eng is not None and eng.handle else 0
 
     # -- noise schedule ----------------------------------------------------------------------------
     def _step_coefficients(self, n_timesteps: int) -> torch.Tensor:
@@ -602,19 +691,35 @@ class UnitSpeech(BaseModule):
             raise ValueError("rng must be 'torch' or 'philox'")
         wt, ws_ = float(text_gradient_scale), float(spk_gradient_scale)
         n_cfg = 1 + (wt > 0.0) + (ws_ > 0.0)
-        out = torch.empty_like(z)
         coef = self._step_coefficients(N)
-        mel = (C.c_float * 2)(float(mel_range[0]), float(mel_range[1])) if mel_range is not None else None
-        with torch.cuda.device(dev):
-            mb = self.micro_batch if self.micro_batch > 0 else 8
-            mb = min(mb, B)
-            nbytes = eng.lib.us_sampler_workspace_bytes(eng.handle, mb, T, n_cfg)
-            wsb = eng.get_workspace(nbytes, dev)
-            rc = eng.lib.us_reverse_diffusion(
-                eng.handle, _dev_ptr(z), _dev_ptr(mask), _dev_ptr(cond), _dev_ptr(spk),
-                _dev_ptr(noise) if noise is not None else None, C.c_uint64(seed), C.c_int64(utt_offset), B, T, N, wt, ws_,
-                C.c_void_p(coef.data_ptr()), mb, mel, _dev_ptr(out), _dev_ptr(wsb), wsb.numel(), _stream())
-        _lib.check(rc, eng.handle, "us_reverse_diffusion")
+        # mel_min / mel_max: python numbers or one-element tensors ride in the sampler's last pass; per-bin tensors ([F], [F, 1],
+        # [1, F, 1]: data.py:57 stores `torch.load(..).unsqueeze(-1)`) broadcast as the reference's tensor expression does
+        mel, mel_tensors = None, None
+        if mel_range is not None:
+            lo, hi = mel_range
+            if any(isinstance(v, torch.Tensor) and v.numel() > 1 for v in (lo, hi)):
+                mel_tensors = tuple(torch.as_tensor(v, dtype=torch.float32, device=dev) for v in (lo, hi))
+                mel_tensors = tuple(v.view(F, 1) if v.dim() == 1 and v.numel() == F else v for v in mel_tensors)
+            else:
+                mel = (C.c_float * 2)(float(lo), float(hi))
+
+        def run(e):
+            out = torch.empty_like(z)
+            with torch.cuda.device(dev):
+                mb = self.micro_batch if self.micro_batch > 0 else 8
+                mb = min(mb, B)
+                nbytes = e.lib.us_sampler_workspace_bytes(e.handle, mb, T, n_cfg)
+                wsb = e.get_workspace(nbytes, dev)
+                rc = e.lib.us_reverse_diffusion(
+                    e.handle, _dev_ptr(z), _dev_ptr(mask), _dev_ptr(cond), _dev_ptr(spk),
+                    _dev_ptr(noise) if noise is not None else None, C.c_uint64(seed), C.c_int64(utt_offset), B, T, N, wt, ws_,
+                    C.c_void_p(coef.data_ptr()), mb, mel, _dev_ptr(out), _dev_ptr(wsb), wsb.numel(), _stream())
+            _lib.check(rc, e.handle, "us_reverse_diffusion")
+            return out
+
+        out = _run_checked(eng, run, lambda: self._sync(dev, exact=True), self.range_check, "UnitSpeech.reverse_diffusion")
+        if mel_tensors is not None:
+            out = (out + 1) / 2 * (mel_tensors[1] - mel_tensors[0]) + mel_tensors[0]      # inference.py:140
         return out
 
     @torch.no_grad()
@@ -662,6 +767,9 @@ class UnitSpeech(BaseModule):
         dev = y.device
         B, Ly = y.shape[0], y.shape[-1]
         lens = [int(v) for v in y_lengths.cpu().tolist()]
+        if len(lens) != B or any(n <= 0 or n > Ly for n in lens):
+            # the reference's slicing (`y[i, :, cut_lower:cut_upper]`, :464-472) would raise on such a length; the kernel would read past y
+            raise ValueError(f"fine_tune: y_lengths {lens} must hold {B} values in [1, {Ly}] (y has {Ly} frames)")
         starts = [random.choice(range(0, n - segment_size)) if n > segment_size else 0 for n in lens]
         counts = [min(n, segment_size) for n in lens]
         if attn.dim() == 4:
