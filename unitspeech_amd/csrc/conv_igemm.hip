@@ -687,6 +687,63 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // wave instruction, 4x fewer memory instructions than the native layout (the epilogue was half the time of the K=128
   // 1x1 convolutions and 11 % of the level-0 3x3s).
   __syncthreads();                                   // every wave is done with the operand buffers
+  if constexpr (!WINO && MB == 1) {
+    if (a.attn_part_ctx && n0 >= TN) {
+      // to_qkv column tiles 1 / 2: this wave's two 32-column blocks are k_h and v_h of head h for 32 of the tile's 64 rows
+      // (qkv_src_row).  Linear attention (unitspeech/unitspeech.py:91-92): k = softmax over ALL n positions, ctx = k v^T; here the
+      // online-softmax partial of the 64 rows: column maxima m, P = exp(k - m), s = sum_rows P, ctx = P^T v.  A 32x32 accumulator
+      // block has its column on the lane and its rows in the registers, which is exactly the operand layout of
+      // v_mfma_f32_32x32x2_f32 for a product that sums over ROWS: register r of P and of V go in as they stand.
+      const int h = (n0 / TN - 1) * 2 + wn;
+      float* xm = smem;                  // [wn][wm][32]  column maxima of each wave
+      float* xs = smem + 128;            // [wn][32]      column sums of wave wm = 1
+      float* xc = smem + 256;            // [wn][32][32]  ctx of wave wm = 1
+      const int mrow0 = m0 + wm * 32 + 4 * hh;
+      float kmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = mrow0 + (r & 3) + 8 * (r >> 2) < Ms;
+        kmax = fmaxf(kmax, ok ? acc[0][0][r] : -INFINITY);
+      }
+      kmax = fmaxf(kmax, __shfl_xor(kmax, 32));
+      if (hh == 0) xm[(wn * 2 + wm) * 32 + l32] = kmax;
+      __syncthreads();
+      const float mcol = fmaxf(xm[(wn * 2) * 32 + l32], xm[(wn * 2 + 1) * 32 + l32]);     // finite: row m0 is always valid
+      f32x16 ctx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+      float ssum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = mrow0 + (r & 3) + 8 * (r >> 2) < Ms;
+        const float p = ok ? expf(acc[0][0][r] - mcol) : 0.f;
+        const float v = ok ? acc[0][1][r] : 0.f;
+        ssum += p;
+        ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v, ctx, 0, 0, 0);
+      }
+      ssum += __shfl_xor(ssum, 32);
+      if (wm == 1) {
+        if (hh == 0) xs[wn * 32 + l32] = ssum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[wn * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + l32] = ctx[r];
+      }
+      __syncthreads();
+      if (wm == 0) {
+        const long long blk = (long long)b * a.attn_nchunks + bx;
+        float* pc = a.attn_part_ctx + (blk * kHeads + h) * (kDimHead * kDimHead);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          pc[d * kDimHead + l32] = ctx[r] + xc[wn * 1024 + d * 32 + l32];
+        }
+        if (hh == 0) {
+          a.attn_part_m[blk * kHidden + h * kDimHead + l32] = mcol;
+          a.attn_part_s[blk * kHidden + h * kDimHead + l32] = ssum + xs[wn * 32 + l32];
+        }
+      }
+      return;
+    }
+  }
   float* tr = smem + wave * (32 * 36);               // 32 rows x (32 + 4 pad) floats per wave
   const bool need_xy = !dense || om_b != nullptr;
   const int trow = lane >> 3, tc4 = (lane & 7) * 4;  // read-back role: row trow + 8k, channels tc4..tc4+3
@@ -694,6 +751,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   const bool edge = WINO && (((a.Hout | a.Wout) & 1) != 0);
   // bias of this wave's two 32-column blocks, loaded ONCE: a global load inside the block loop would make every block wait
   // (vmcnt retires in order) for the previous block's stores to reach memory
+  bool out_over = false;          // out_split: a stored value beyond the fp16 range
   float bias_col[2];
   f32x4 bias_quad[2];
 #pragma unroll
@@ -749,12 +807,28 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
           v = (v + b4) * alpha;
           if (add_b) v += *reinterpret_cast<const f32x4*>(add_b + pix * a.add_ld + n);
           if (om_b) v *= om_b[ox * a.omask_step];
-          *reinterpret_cast<f32x4*>(out_b + pix * a.out_ld + n) = v;
+          if (a.out_split) {
+            typedef _Float16 half4o __attribute__((ext_vector_type(4)));
+            half4o hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              us_half h_, l_;
+              split_f16x3(v[q], h_, l_, out_over);
+              hi[q] = h_;
+              lo[q] = l_;
+            }
+            _Float16* oh = reinterpret_cast<_Float16*>(out_b + pix * a.out_ld) + 2 * (n & ~7) + (n & 7);
+            *reinterpret_cast<half4o*>(oh) = hi;
+            *reinterpret_cast<half4o*>(oh + 8) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(out_b + pix * a.out_ld + n) = v;
+          }
         }
       }
     }
   }
   }   // output positions
+  if (a.out_split) range_report(a.range_flag, out_over, kRangeAct);
   if (a.stats) {
     // GroupNorm(8) partial sums of the conv output (pre-alpha/add/mask); Cout/8 is a power of two (host-checked)
     const int cg = a.Cout / kGroups;
@@ -901,11 +975,16 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     // f16x3: the weights are pre-split; f16 = 1: so is the A operand (Winograd-domain GEMMs, planes written by the input
     // transforms); f16 = 2: A is a plain fp32 activation tensor, split in the kernel (any tap geometry)
     if (a.bk != 32) return hipErrorInvalidValue;
-    if (a.f16 == 1 && a.ntaps == 1 && a.istride == 1 && !a.bias && !a.add) a.splitk_ws = nullptr;    // Winograd-domain GEMMs
+    if (a.f16 == 1 && !a.direct_presplit && a.ntaps == 1 && a.istride == 1 && !a.bias && !a.add) a.splitk_ws = nullptr;    // Winograd-domain GEMMs
     if (tm == 0 && g_f16_tm > 0) tm = g_f16_tm;
     if (tm == 0) {
-      if (a.f16 == 1 && a.ntaps > 1) {
-        tm = 64;      // a direct convolution whose producer wrote the two-plane form: same rule as the in-kernel split below
+      if (a.f16 == 1 && (a.ntaps > 1 || a.direct_presplit)) {
+        // a direct convolution whose producer wrote the two-plane form: no split work in the kernel, so the 128-row tile (wave tile
+        // 64 x 64, two workgroups per CU) wins over three 64-row ones: +1.4 % end to end with four such convolutions, 256 rows +1.0 %
+        // (US_TM_PRESPLIT overrides).  A function of the item's geometry only, like the rule below.
+        static int tm_pre = -1;
+        if (tm_pre < 0) { const char* e = getenv("US_TM_PRESPLIT"); tm_pre = e ? atoi(e) : 0; }
+        tm = tm_pre > 0 ? tm_pre : ((long long)a.Hs * a.Ws >= 512 ? 128 : 64);
       } else if (a.f16 == 1) {
         // Winograd-domain GEMMs (all items of a frequency in one M range): the largest tile that still fills the chip
         const long long per256 = (long long)((a.Hs * a.Ws + 255) / 256) * nt * a.B;
@@ -915,6 +994,11 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // U-Net shape (tools/conv_bench: 272 vs 251 vs 210 TFLOP/s on the level-0 3x3).  Never a function of the batch, so that
         // the split-K slicing below, hence the summation order, does not depend on what an utterance is batched with.
         tm = 64;
+        static int tm_1x1 = -1, tm_taps = -1;        // experiment knobs: US_TM_1X1 / US_TM_TAPS = 64 | 128 | 256
+        if (tm_1x1 < 0) { const char* e = getenv("US_TM_1X1"); tm_1x1 = e ? atoi(e) : 0; }
+        if (tm_taps < 0) { const char* e = getenv("US_TM_TAPS"); tm_taps = e ? atoi(e) : 0; }
+        if (a.ntaps == 1 && a.nphase <= 1 && tm_1x1 > 0 && (long long)a.Hs * a.Ws >= 4 * tm_1x1) tm = tm_1x1;
+        if ((a.ntaps > 1 || a.nphase > 1) && tm_taps > 0 && (long long)a.Hs * a.Ws >= 4 * tm_taps) tm = tm_taps;
       }
     }
   }
@@ -922,6 +1006,18 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     // fused Winograd output transform: ntaps = 1, ostep = 2, Hs x Ws = tile grid, Hout x Wout = image, no split-K
     if (a.ntaps != 1 || a.ostep != 2 || a.istride != 1 || a.alpha) return hipErrorInvalidValue;
     if (2 * a.Hs < a.Hout || 2 * a.Ws < a.Wout) return hipErrorInvalidValue;
+    tm = 64;
+    a.splitk_ws = nullptr;
+  }
+  if (a.out_split) {
+    if (a.Cout % 8 != 0 || a.out_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(a.out) & 31) != 0) return hipErrorInvalidValue;
+    a.splitk_ws = nullptr;        // (the slab finish writes fp32)
+  }
+  if (a.attn_part_ctx) {
+    // to_qkv with the attention reduction in the epilogue: three 128-column tiles, 64-row tiles (one chunk of partials each), one pass
+    if (a.Cout != 3 * kHidden || a.ntaps != 1 || a.istride != 1 || a.ostep != 1 || a.wino_out || a.nphase > 1 || a.bias || a.add || a.alpha ||
+        a.stats || a.f16 == 1 || !a.attn_part_m || !a.attn_part_s || a.attn_nchunks != (a.Hs * a.Ws + 63) / 64)
+      return hipErrorInvalidValue;
     tm = 64;
     a.splitk_ws = nullptr;
   }
@@ -990,8 +1086,14 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
 }
 
 // ---- weight repack --------------------------------------------------------------------------------
+__device__ __forceinline__ int qkv_src_row_dev(int cp) {       // == qkv_src_row (kernels.h)
+  if (cp < kHidden) return cp;
+  const int t = cp - kHidden, h = t >> 6, w = t & 63;
+  return (w < kDimHead ? kHidden : 2 * kHidden) + h * kDimHead + (w & (kDimHead - 1));
+}
+
 __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int KH, int KW,
-                                        int oihw, int bk) {
+                                        int oihw, int bk, int qkv_rows) {
   const long long total = (long long)KH * KW * Cout * Cin;
   const int nchunk = Cin / bk;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -1002,6 +1104,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __
     int tap = (int)(t / nchunk);
     int ci = ch * bk + k;
     int ky = tap / KW, kx = tap % KW;
+    if (qkv_rows) co = qkv_src_row_dev(co);
     long long si = oihw ? (((long long)co * Cin + ci) * KH + ky) * KW + kx
                         : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
     dst[i] = src[si];
@@ -1012,14 +1115,15 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __
 // One thread = one 32-byte piece (8 input channels of one (tap, output channel)): two 16-byte stores.
 typedef _Float16 half8p __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void pack_conv_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin,
-                                                                   int KH, int KW, int oihw, unsigned* range_flag) {
+                                                                   int KH, int KW, int oihw, unsigned* range_flag, int qkv_rows) {
   bool over = false;
   const long long total = (long long)KH * KW * Cout * (Cin / 8);
   const int nchunk = Cin / 32;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int g4 = (int)(i & 3);
     long long t = i >> 2;
-    const int co = (int)(t % Cout); t /= Cout;
+    int co = (int)(t % Cout); t /= Cout;
+    if (qkv_rows) co = qkv_src_row_dev(co);
     const int ch = (int)(t % nchunk);
     const int tap = (int)(t / nchunk);
     const int ky = tap / KW, kx = tap % KW;
@@ -1040,23 +1144,24 @@ __global__ __launch_bounds__(256) void pack_conv_weight_f16_kernel(const float* 
   range_report(range_flag, over, kRangeWeight);
 }
 
-hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s) {
-  if (Cin % 32 != 0) return hipErrorInvalidValue;
+hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s,
+                                       bool qkv_rows) {
+  if (Cin % 32 != 0 || (qkv_rows && Cout != 3 * kHidden)) return hipErrorInvalidValue;
   long long total = (long long)KH * KW * Cout * (Cin / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_conv_weight_f16_kernel, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), Cout, Cin, KH, KW,
-                     oihw ? 1 : 0, current_range_flag());
+                     oihw ? 1 : 0, current_range_flag(), qkv_rows ? 1 : 0);
   return hipGetLastError();
 }
 
 hipError_t launch_pack_conv_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk,
-                                   hipStream_t s) {
-  if (Cin % bk != 0) return hipErrorInvalidValue;
+                                   hipStream_t s, bool qkv_rows) {
+  if (Cin % bk != 0 || (qkv_rows && Cout != 3 * kHidden)) return hipErrorInvalidValue;
   long long total = (long long)KH * KW * Cout * Cin;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, KH, KW, oihw ? 1 : 0, bk);
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, KH, KW, oihw ? 1 : 0, bk, qkv_rows ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -46,6 +46,8 @@ struct Slot {
   DevBuf wino_dg;        // ... and of the rotated, channel-swapped filter for the data gradient, [16][Cout/bk_dg][Cin][bk_dg]
   bool want_wino = false;
   bool dg_as_1x1 = false;  // RAW [Cout][Cin][1][1] tensor that also needs a dgrad pack (attention to_out)
+  bool is_qkv = false;     // attention to_qkv: a second forward pack with the rows in qkv_src_row() order (ConvArgs::attn_part_ctx)
+  DevBuf qkv_rows;         // ... in the same operand form as `buf` (f16x3 planes or fp32)
   float* grad = nullptr; // caller-owned gradient buffer (reference layout) for the current backward call
   bool loaded = false;
 };
@@ -109,6 +111,7 @@ struct us_decoder {
   long long wino_fuse_small_kn = 512 * 256;      // US_WINO_FUSE_SMALL_KN elements per frequency
   bool wino_fuse_gn = true;  // US_WINO_FUSE_GN=0: block1's gn_apply as its own pass
   bool presplit = true;      // US_PRESPLIT=0: block1's GroupNorm output stays fp32 for the direct block2 convolution (split in the kernel)
+  bool attn_fuse = true;     // US_ATTN_FUSE=0: to_qkv writes q | k | v and attn_ctx_partial_kernel re-reads k, v (the training path's form)
   bool xcd_z = true;         // US_XCD_Z=0: the Winograd-domain GEMMs dealt to the XCDs by tile only, not by whole frequencies (A/B)
   bool wino_narrow = false; // US_WINO_NARROW=1: Winograd also for convolutions with cout <= dim below level 0 (add_resnet)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
@@ -239,6 +242,7 @@ struct us_decoder {
     a.dim = dim; a.level = level;
     a.g = add(p + ".fn.g", {1});
     a.qkv = add_conv(p + ".fn.fn.to_qkv", 3 * kHidden, dim, 1, false);
+    a.qkv.w->is_qkv = true;
     a.out_w = add(p + ".fn.fn.to_out.weight", {dim, kHidden, 1, 1});
     a.out_w->dg_as_1x1 = true;
     a.out_w->bk_dg = pick_bk(dim);
@@ -377,7 +381,7 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false
     if (l > 0) b.CAT[l] = A.alloc<float>(B * n * 2 * c);
   }
   b.U0 = A.alloc<float>(B * (size_t)F * T * h->C[0]);
-  size_t nch = attn_nchunks((int)max_n);
+  size_t nch = (max_n + 63) / 64;        // 64-row chunks of the fused to_qkv epilogue (the separate kernel's are 128 rows)
   b.part_ctx = A.alloc<float>(B * nch * kHeads * kDimHead * kDimHead);
   b.part_m = A.alloc<float>(B * nch * kHidden);
   b.part_s = A.alloc<float>(B * nch * kHidden);
@@ -559,6 +563,7 @@ hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
   if (in_split) {
     if (a.f16 != 2) return hipErrorInvalidValue;
     a.f16 = 1;
+    a.direct_presplit = 1;
   }
   a.ntaps = 9;
   for (int ky = 0; ky < 3; ++ky)
@@ -567,11 +572,18 @@ hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
   return run_conv(e, a);
 }
 
+// in_split: `in` holds the two-plane fp16 form (its producer stored it with out_split; f16x3 convolutions only); out_split: store it so
 hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, bool mask_out, float* out, int out_ld,
                    const float* add, int add_ld, const float* alpha, const float* wt_override, long long wt_bstride,
-                   const float* bias_override) {
+                   const float* bias_override, bool in_split = false, bool out_split = false) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
+  if (in_split) {
+    if (a.f16 != 2) return hipErrorInvalidValue;
+    a.f16 = 1;
+    a.direct_presplit = 1;
+  }
+  a.out_split = out_split ? 1 : 0;
   a.ntaps = 1;
   a.set_tap(0, 0, 0, 0);
   if (mask_out) set_omask(e, a, level);
@@ -580,9 +592,14 @@ hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
   return run_conv(e, a);
 }
 
-hipError_t conv_down(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld) {
+hipError_t conv_down(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, bool in_split = false) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H / 2, W / 2);
+  if (in_split) {
+    if (a.f16 != 2) return hipErrorInvalidValue;
+    a.f16 = 1;
+    a.direct_presplit = 1;
+  }
   a.ntaps = 9;
   a.istride = 2;
   for (int ky = 0; ky < 3; ++ky)
@@ -593,12 +610,19 @@ hipError_t conv_down(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int
 
 // ConvTranspose2d(k=4, s=2, p=1): output row oy = 2*iy - 1 + ky.  Output phase py = oy & 1 receives exactly two
 // kernel rows: py=0 -> (ky=1, iy=m), (ky=3, iy=m-1); py=1 -> (ky=2, iy=m), (ky=0, iy=m+1)   (same along x).
-hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld) {
+hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, float* out, int out_ld, bool in_split = false,
+                   bool out_split = false) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   static const int KY[2][2] = {{1, 3}, {2, 0}};
   static const int DY[2][2] = {{0, -1}, {0, 1}};
   // all four output phases in one launch (ConvArgs::nphase)
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, 2 * H, 2 * W);
+  if (in_split) {
+    if (a.f16 != 2) return hipErrorInvalidValue;
+    a.f16 = 1;
+    a.direct_presplit = 1;
+  }
+  a.out_split = out_split ? 1 : 0;
   a.Hs = H; a.Ws = W; a.ostep = 2;
   a.ntaps = 4;
   a.nphase = 4;
@@ -644,7 +668,8 @@ inline bool direct_presplit(EvalCtx& e, const ConvW& w, int C, int tmp_ld) {
 // ResnetBlock (unitspeech/unitspeech.py:58-75).  `in` must already be masked.  mask_out: the result is only consumed
 // through `x * mask` (next ResnetBlock / concat), so the mask is applied to what is stored; false when the consumer
 // is the attention, which reads the raw tensor (padded frames included, :91).
-hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, float* out, int out_ld, bool mask_out) {
+// in_split: `in` is in the two-plane fp16 form (only legal when block1's convolution and res_conv are direct f16x3 convolutions: resnet_takes_split())
+hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, float* out, int out_ld, bool mask_out, bool in_split = false) {
   Buffers& b = *e.b;
   const int l = r.level;
   float* S1 = b.S1[l];
@@ -652,7 +677,8 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
   const float* tproj = b.tproj + b.tproj_off[r.index];
   double* st1 = next_stats(e);
   double* st2 = next_stats(e);
-  CK(conv3x3(e, r.c1, in, in_ld, l, S1, r.cout, st1));
+  if (in_split && !r.has_res) return hipErrorInvalidValue;      // the identity residual would need the fp32 tensor
+  CK(conv3x3(e, r.c1, in, in_ld, l, S1, r.cout, st1, in_split));
   if (r.c2.w->wino.p && b.wino_v && e.h->wino_fuse_gn && gn_wino_input_supported(r.cout)) {
     // block1's GroupNorm + Mish + time embedding (pre-masked for block2's `x * mask`, :54) evaluated inside the Winograd input
     // transform of block2's conv: h1 is never written
@@ -672,23 +698,48 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
   }
   if (r.has_res) {
     CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, nullptr, 0, false, false, out, out_ld));
-    CK(conv1x1(e, r.res, in, in_ld, l, mask_out, out, out_ld, out, out_ld, nullptr, nullptr, 0, nullptr));
+    CK(conv1x1(e, r.res, in, in_ld, l, mask_out, out, out_ld, out, out_ld, nullptr, nullptr, 0, nullptr, in_split));
   } else {
     CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, in, in_ld, false, mask_out, out, out_ld));
   }
   return hipSuccess;
 }
 
+// a ResnetBlock whose two readers of its input (block1's 3x3, res_conv) are both direct f16x3 convolutions can take that input pre-split
+inline bool resnet_takes_split(EvalCtx& e, const ResnetW& r) {
+  return e.h->presplit && !r.first && r.has_res && !(r.c1.w->wino.p && e.b->wino_v) && r.c1.w->direct_f16 && r.res.w->direct_f16;
+}
+
 // Residual(Rezero(LinearAttention)) (unitspeech/unitspeech.py:78-106)
-hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, float* out, int out_ld) {
+// out_split: store the result in the two-plane fp16 form (every consumer is a direct f16x3 convolution)
+hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, float* out, int out_ld, bool out_split = false) {
   Buffers& b = *e.b;
   const int l = at.level;
   const int n = (e.h->cfg.n_feats >> l) * (e.T >> l);
   const int nch = attn_nchunks(n);
   float* qkv = b.QKV[l];
-  CK(conv1x1(e, at.qkv, in, in_ld, l, false, qkv, 3 * kHidden, nullptr, 0, nullptr, nullptr, 0, nullptr));
-  CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
-  CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, b.colM, b.colS, b.ctx_split, e.s));
+  int q_ld = 3 * kHidden;
+  bool q_split = false;
+  if (e.h->attn_fuse && at.qkv.w->qkv_rows.p) {
+    // to_qkv with the n-reduction in its epilogue: only q is written ([n][128]); chunks of 64 rows (ConvArgs::attn_part_ctx)
+    const int H = e.h->cfg.n_feats >> l, W = e.T >> l;
+    const int nch64 = (n + 63) / 64;
+    q_ld = kHidden;
+    ConvArgs a = base_args(e, at.qkv, in, in_ld, H, W, qkv, q_ld, H, W);
+    a.wt = at.qkv.w->qkv_rows.p;
+    a.ntaps = 1;
+    a.set_tap(0, 0, 0, 0);
+    a.attn_part_ctx = b.part_ctx; a.attn_part_m = b.part_m; a.attn_part_s = b.part_s; a.attn_nchunks = nch64;
+    // q has one reader, the folded to_out convolution below: where that runs as f16x3 it takes q pre-split
+    q_split = e.h->presplit && e.h->f16x3 && e.h->f16x3_direct && a.f16 == 2;
+    a.out_split = q_split ? 1 : 0;
+    CK(run_conv(e, a));
+    CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch64, b.ctx, b.colM, b.colS, b.ctx_split, e.s));
+  } else {
+    CK(conv1x1(e, at.qkv, in, in_ld, l, false, qkv, 3 * kHidden, nullptr, 0, nullptr, nullptr, 0, nullptr));
+    CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
+    CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, b.colM, b.colS, b.ctx_split, e.s));
+  }
   const int bk = pick_bk(kHidden);
   const bool f16 = e.h->f16x3 && e.h->f16x3_direct;
   CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s, f16));
@@ -698,8 +749,8 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   tmp.bk = bk; tmp.buf.p = b.weff; tmp.direct_f16 = f16;
   eff.w = &tmp; eff.b = nullptr;
   // every consumer of an attention output masks it (Downsample / Upsample input, skip concat, mid blocks)
-  return conv1x1(e, eff, qkv, 3 * kHidden, l, true, out, out_ld, in, in_ld, at.g->buf.p, b.weff, (long long)at.dim * kHidden,
-                 at.out_b->buf.p);
+  return conv1x1(e, eff, qkv, q_ld, l, true, out, out_ld, in, in_ld, at.g->buf.p, b.weff, (long long)at.dim * kHidden,
+                 at.out_b->buf.p, q_split, out_split);
 }
 
 hipError_t time_embedding(EvalCtx& e, const float* t, const float* spk) {
@@ -753,6 +804,26 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   if (!b.tproj_ready) CK(time_embedding(e, t, spk));
   CK(launch_stack_inputs(x, Bx, mu, Bmu, n_text_uncond, h->text_uncon->buf.p, e.mask, e.Bm, b.in2, e.Bp, F, T, e.s));
 
+  // Tensors that only direct f16x3 convolutions read are stored in the two-plane fp16 form by their producer's epilogue (no split work
+  // in the consumers, which then run the 128-row tile):
+  //   hid_split[l]  level l's attention output.  Level 0: its one reader is the Downsample (the level-0 skip is never popped,
+  //                 unitspeech.py:180,190-192).  Deeper: the Downsample plus the up path's first ResnetBlock (the concat's second half),
+  //                 which qualifies where that block runs direct (resnet_takes_split: the narrow last up level); the concat's first
+  //                 half, the Upsample output of the level below, is then stored the same way.
+  //   up_split[l]   the up path's attention output at level l: its one reader is the Upsample.
+  //   fin_split     the last Upsample's output: its one reader is the final Block's convolution.
+  std::vector<char> hid_split(L, 0), up_split(L, 0);
+  bool fin_split = false;
+  if (h->presplit && h->f16x3 && h->f16x3_direct && h->attn_fuse) {
+    for (int l = 0; l < L; ++l) {
+      auto& d = h->downs[l];
+      if (!d.has_ds || !d.ds.conv.w->direct_f16 || h->C[l] % 8 != 0) continue;
+      if (l == 0) hid_split[0] = 1;
+      else if (l <= L - 2) hid_split[l] = resnet_takes_split(e, h->ups[L - 1 - l].r1) && h->ups[L - 1 - l - 1].us.conv.w->direct_f16 ? 1 : 0;
+    }
+    for (int u = 0; u < L - 1; ++u) up_split[h->ups[u].r1.level] = h->ups[u].us.conv.w->direct_f16 ? 1 : 0;
+    fin_split = L > 1 && !(h->final_conv3.w->wino.p && b.wino_v) && h->final_conv3.w->direct_f16 && h->ups[L - 2].us.conv.w->direct_f16;
+  }
   const float* cur = nullptr;
   int cur_ld = 0;
   for (int l = 0; l < L; ++l) {
@@ -785,9 +856,9 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
     CK(resnet(e, d.r2, b.P[l], c, b.Q[l], c, false));
     float* hid = l == 0 ? b.P[0] : b.CAT[l] + c;
     int hid_ld = l == 0 ? c : 2 * c;
-    CK(attention(e, d.a, b.Q[l], c, hid, hid_ld));
+    CK(attention(e, d.a, b.Q[l], c, hid, hid_ld, hid_split[l]));
     if (d.has_ds) {
-      CK(conv_down(e, d.ds.conv, hid, hid_ld, l, b.D[l + 1], c));
+      CK(conv_down(e, d.ds.conv, hid, hid_ld, l, b.D[l + 1], c, hid_split[l]));
       cur = b.D[l + 1];
       cur_ld = c;
     } else {
@@ -805,19 +876,19 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   for (int u = 0; u < L - 1; ++u) {
     auto& up = h->ups[u];
     const int l = up.r1.level, co = up.r1.cout;
-    CK(resnet(e, up.r1, b.CAT[l], 2 * h->C[l], b.P[l], co, true));
+    CK(resnet(e, up.r1, b.CAT[l], 2 * h->C[l], b.P[l], co, true, l <= L - 2 && hid_split[l]));
     CK(resnet(e, up.r2, b.P[l], co, b.Q[l], co, false));
-    CK(attention(e, up.a, b.Q[l], co, b.P[l], co));
+    CK(attention(e, up.a, b.Q[l], co, b.P[l], co, up_split[l]));
     float* dst = (l - 1 >= 1) ? b.CAT[l - 1] : b.U0;
     int dst_ld = (l - 1 >= 1) ? 2 * h->C[l - 1] : h->C[0];
-    CK(conv_up(e, up.us.conv, b.P[l], co, l, dst, dst_ld));
+    CK(conv_up(e, up.us.conv, b.P[l], co, l, dst, dst_ld, up_split[l], (l - 1 >= 1) ? hid_split[l - 1] != 0 : fin_split));
     fin = dst;
     fin_ld = dst_ld;
   }
   // final Block + 1x1 projection (unitspeech/unitspeech.py:198-201)
   double* stf = next_stats(e);
   const int c0 = h->C[0];
-  CK(conv3x3(e, h->final_conv3, fin, fin_ld, 0, b.S1[0], c0, stf));
+  CK(conv3x3(e, h->final_conv3, fin, fin_ld, 0, b.S1[0], c0, stf, fin_split));
   CK(gn_apply(e, b.S1[0], 0, c0, stf, h->final_g, h->final_b, nullptr, nullptr, 0, false, false, b.S1[0], c0));
   CK(launch_final_conv(b.S1[0], c0, h->final_w1->buf.p, h->final_b1->buf.p, e.mask, T, e.Bm, out, e.Bp, F, T, c0, e.s));
   return hipSuccess;
@@ -967,6 +1038,7 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   if (const char* wf = getenv("US_WINO_FUSE_GN")) h->wino_fuse_gn = atoi(wf) != 0;
   if (const char* wf = getenv("US_XCD_Z")) h->xcd_z = atoi(wf) != 0;
   if (const char* wf = getenv("US_PRESPLIT")) h->presplit = atoi(wf) != 0;
+  if (const char* wf = getenv("US_ATTN_FUSE")) h->attn_fuse = atoi(wf) != 0;
   if (flags & US_CREATE_EXACT_FP32) h->f16x3 = false;
   h->exact = !h->f16x3;
   h->build();
@@ -997,6 +1069,10 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
         ok = hipMalloc(reinterpret_cast<void**>(&s->dg.p), s->dg.n * sizeof(float)) == hipSuccess;
       }
     }
+    if (ok && s->is_qkv) {
+      s->qkv_rows.n = s->buf.n;
+      ok = hipMalloc(reinterpret_cast<void**>(&s->qkv_rows.p), s->qkv_rows.n * sizeof(float)) == hipSuccess;
+    }
     if (ok && s->want_wino) {
       s->wino.n = s->wino_dg.n = (size_t)16 * s->shape[0] * s->shape[1];
       ok = hipMalloc(reinterpret_cast<void**>(&s->wino.p), s->wino.n * sizeof(float)) == hipSuccess &&
@@ -1017,7 +1093,7 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
     }
     if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); }
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); if (t->qkv_rows.p) (void)hipFree(t->qkv_rows.p); }
       return US_EHIP;
     }
   }
@@ -1040,7 +1116,7 @@ int us_decoder_flush_weights(us_handle h, us_stream stream) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); }
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); if (s->qkv_rows.p) (void)hipFree(s->qkv_rows.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   if (h->copy_tab_dev) (void)hipFree(h->copy_tab_dev);
   if (h->grad_tab_dev) (void)hipFree(h->grad_tab_dev);
@@ -1101,6 +1177,8 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
       else if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
       else if (s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, st));
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
+      if (s->qkv_rows.p && s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->qkv_rows.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, st, true));
+      else if (s->qkv_rows.p) US_HIP(h, launch_pack_conv_weight(data, s->qkv_rows.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk, st, true));
       if (s->wino_dg.p && s->wino_dg_f16) US_HIP(h, launch_wino_pack_weight_f16(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], st, true));
       else if (s->wino_dg.p) US_HIP(h, launch_wino_pack_weight(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], s->bk_dg, st, true));
       else if (s->dg_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, st));

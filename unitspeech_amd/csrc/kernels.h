@@ -106,6 +106,19 @@ struct ConvArgs {
   float* splitk_ws;      // optional scratch for split-K partial slabs (splitk_ws_floats floats); null disables split-K
   long long splitk_ws_floats;
   unsigned* range_flag;  // set by the launcher (current_range_flag()): where an in-kernel f16x3 split reports an operand beyond the fp16 range
+  int direct_presplit;   // f16 = 1 on a DIRECT convolution (its producer stored the input with out_split), as opposed to a Winograd-domain
+                         // GEMM: the tile follows the direct rule (a function of the item's geometry only, never of the batch)
+  int out_split;         // 1: the stored tensor is the two-plane fp16 form (per 8 channels 8 hi | 8 lo, same bytes as fp32; Cout, out_ld and
+                         // the channel offset of `out` multiples of 8) that an f16x3 convolution takes as a pre-split A operand (f16 = 1): for
+                         // tensors whose every consumer is such a convolution (no split-K; a value beyond the fp16 range is reported)
+  // to_qkv of the linear attention with the n-reduction in its epilogue (inference): `wt` holds the rows in qkv_src_row() order, so
+  // column tile 0 is q (stored to `out`, ld 128) and every wave of tiles 1 / 2 holds k_h | v_h of one head: it takes the column
+  // maxima, exp(k - m), the column sums and ctx_h = exp(k - m)^T v over the workgroup's 64 rows (accumulator registers as MFMA
+  // operands, no LDS transpose) and writes them as chunk (item, row tile) of the online-softmax partials; k and v never reach memory
+  float* attn_part_ctx;  // [B][attn_nchunks][4][32][32]; non-null selects the mode (single pass, 64-row tiles)
+  float* attn_part_m;    // [B][attn_nchunks][128]
+  float* attn_part_s;    // [B][attn_nchunks][128]
+  int attn_nchunks;      // ceil(Hs * Ws / 64)
 #ifdef US_STAMP
   unsigned long long* stamp_out;   // diagnostic build only: per (workgroup, wave) {cycles at the vmcnt wait, at the barrier, in the body, steps}
 #endif
@@ -140,16 +153,25 @@ __device__ __forceinline__ double stat_read(const double* stats, long long b, in
   return t;
 }
 #endif
+// packed (tile-ordered) row of the attention's to_qkv weight -> the reference's output channel (q | k | v, heads x 32 each,
+// unitspeech/unitspeech.py:89-90): rows 0..127 q; then per head h the 64 rows k_h (32) | v_h (32)
+inline int qkv_src_row(int cp) {
+  if (cp < kHidden) return cp;
+  const int t = cp - kHidden, h = t >> 6, w = t & 63;
+  return (w < kDimHead ? kHidden : 2 * kHidden) + h * kDimHead + (w & (kDimHead - 1));
+}
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 hipError_t conv_igemm_init();   // one-time function attributes (dynamic LDS size)
 
 // Repack reference-layout weights into [tap][Cin/bk][Cout][bk].
 //   oihw = true : src is Conv2d  [Cout][Cin][KH][KW]
 //   oihw = false: src is ConvTranspose2d [Cin][Cout][KH][KW]
+//   qkv_rows: packed row r holds source output channel qkv_src_row(r) (Cout = 384: the attention's to_qkv, see ConvArgs::attn_part_ctx)
 hipError_t launch_pack_conv_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk,
-                                   hipStream_t s);
+                                   hipStream_t s, bool qkv_rows = false);
 // the same pack as two interleaved fp16 planes per value (f16x3 GEMM, bk = 32; same size)
-hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s);
+hipError_t launch_pack_conv_weight_f16(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, hipStream_t s,
+                                       bool qkv_rows = false);
 
 // ---- first layer (2 input channels) ---------------------------------------------------------------
 // in2: [Bp][F][T][2] = (mu, x) already masked; writes conv3x3 (pad 1) -> y[Bp][F*T][C] and the ResnetBlock's
@@ -291,6 +313,7 @@ struct GnBwdArgs {
   float* gy; int gy_ld;              // gradient w.r.t. y
   float* ggamma; float* gbeta;       // [C], accumulated (zeroed by the caller)
   float* gbias;                      // optional [C]: column sums of gy (bias gradient of the producing conv)
+  float* gy_amax;                    // optional zeroed word: receives max |gy| (float bits; launch_wgrad_amax's result without its pass)
   double* gsum;                      // scratch [B][8][2], zeroed by the caller
   int B, H, W, C;
 };

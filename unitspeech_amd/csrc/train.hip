@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   f32x4 ga, be, mean4, rstd4, s14, s24;
   f32x4 ch0 = {0.f, 0.f, 0.f, 0.f}, ch1 = {0.f, 0.f, 0.f, 0.f};    // PASS 1: (sum dz*xn, sum dz); PASS 2: (sum gy, -)
   double g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
+  float gy_max = 0.f;              // PASS 2: max |gy| of this thread (the f16x3 weight-gradient kernel scales gy by it: WgradArgs::gy_amax)
   int cur = -1;
   auto flush = [&]() {
     if (cur < 0) return;
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
       } else {
         o[k] = rstd4[k] * (dz * ga[k] - s14[k] - xn * s24[k]);
         ch0[k] += o[k];
+        gy_max = fmaxf(gy_max, fabsf(o[k]));
       }
     }
     if (PASS == 2) *reinterpret_cast<f32x4*>(ob + p * a.gy_ld + c) = o;
@@ -692,8 +694,14 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
     }
     if (threadIdx.x < kGroups * 2)
       atomicAdd(&a.gsum[((long long)b * kGroups + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], s_grp[threadIdx.x >> 1][threadIdx.x & 1]);
-  } else if (a.gbias) {
-    for (int k = threadIdx.x; k < C; k += 256) atomicAdd(&a.gbias[k], s_ch[0][k]);
+  } else {
+    if (a.gbias)
+      for (int k = threadIdx.x; k < C; k += 256) atomicAdd(&a.gbias[k], s_ch[0][k]);
+    if (a.gy_amax) {               // as wgrad_amax_kernel: non-negative floats order like their bit patterns
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) gy_max = fmaxf(gy_max, __shfl_xor(gy_max, off));
+      if ((threadIdx.x & 63) == 0 && gy_max > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.gy_amax), __float_as_uint(gy_max));
+    }
   }
 }
 
