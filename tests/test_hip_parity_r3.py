@@ -259,8 +259,12 @@ def _hip_grads(sd_np, x0, mask, cond, spk, t, z, exact=False, loss_factor=1.0):
 
 
 def _rel(new, ref, show=3):
+    """(whole-gradient relative L2, median per-tensor relative L2, worst per-tensor relative L2).  One-element tensors (the eight Rezero
+    gains: sums of terms ~1e-3 that cancel down to 1e-6 ... 1e-4) are measured against the LARGEST of them rather than against themselves:
+    their last digits move with the order of the fp32 atomics between two runs of the same code."""
     whole = float(torch.sqrt(sum(((new[n] - ref[n]) ** 2).sum() for n in ref)) / torch.sqrt(sum((ref[n] ** 2).sum() for n in ref)))
-    per = sorted((float((new[n] - ref[n]).norm() / (ref[n].norm() + 1e-300)), n) for n in ref)
+    scal = max([float(ref[n].abs().max()) for n in ref if ref[n].numel() == 1] + [1e-300])
+    per = sorted((float((new[n] - ref[n]).norm() / ((ref[n].norm() if ref[n].numel() > 1 else scal) + 1e-300)), n) for n in ref)
     print("\n  worst tensors: " + ", ".join(f"{n} {e:.1e} (|ref| {float(ref[n].norm()):.1e}, {ref[n].numel()} el.)" for e, n in per[-show:]))
     return whole, per[len(per) // 2][0], per[-1][0]
 
@@ -275,9 +279,7 @@ def test_backward_is_insensitive_to_the_magnitude_of_the_incoming_gradient(sd_np
     small = {n: g * 1e3 for n, g in small.items()}
     whole, median, worst = _rel(small, ref)
     print(f"\nloss x 1e-3 at one crop: whole-gradient relative L2 vs exact fp32 {whole:.2e}, median tensor {median:.2e}, worst {worst:.2e}")
-    # (the worst tensors are the scalar Rezero gains: one-element sums with heavy cancellation, |g| down to 2e-6 here, whose last digits
-    # also move with the order of the fp32 atomics in either run)
-    assert len(ref) == 228 and whole <= 6e-7 and median <= 1.5e-6 and worst <= 1e-3
+    assert len(ref) == 228 and whole <= 6e-7 and median <= 1.5e-6 and worst <= 1e-4
 
 
 def test_pretraining_batch_loss_and_every_gradient_vs_oracle_autograd(sd_np):

@@ -156,6 +156,156 @@ hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, 
   return hipGetLastError();
 }
 
+// ---- merge of the chunk partials in two launches (replaces stats + accum + reduce [+ weff]) -------------------------------------
+// Hierarchical online softmax: launch 1, grid (nrange, B*heads): block (r, b, h) folds the chunks of range r with the range's own
+// column maxima M_r[d]: S_r[d] = sum_c s_c[d] exp(m_c[d] - M_r[d]), ctx_r[d][e] = sum_c exp(m_c[d] - M_r[d]) part_c[d][e] (fixed
+// order: reproducible).  Launch 2, grid (B*heads): M = max_r M_r, S = sum_r S_r exp(M_r - M), ctx = sum_r ctx_r exp(M_r - M) / S ->
+// ctx, colM, colS, and (inference) the head's slice of the folded to_out weights W_eff straight after, while ctx is still in LDS.
+__global__ __launch_bounds__(1024) void attn_merge_kernel(const float* __restrict__ part_ctx, const float* __restrict__ part_m,
+                                                          const float* __restrict__ part_s, int nchunks, int per_range,
+                                                          float* __restrict__ r_ctx, float* __restrict__ r_m, float* __restrict__ r_s) {
+  __shared__ float s_m[64][kDimHead + 1];         // column maxima of up to 64 chunks at a time
+  __shared__ float s_M[kDimHead], s_S[kDimHead];
+  const int bh = blockIdx.y, b = bh / kHeads, h = bh % kHeads;
+  const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
+  const int lo = blockIdx.x * per_range;
+  const int hi = min(lo + per_range, nchunks);
+  const float* pm = part_m + (long long)b * nchunks * kHidden + h * kDimHead;
+  const float* ps = part_s + (long long)b * nchunks * kHidden + h * kDimHead;
+  const float* pc = part_ctx + ((long long)b * nchunks * kHeads + h) * (kDimHead * kDimHead) + d * kDimHead + e;
+  // range maximum per column d: thread (d, e) scans chunks lo + e, lo + e + 32, ... (each row of part_m is read as 32 contiguous floats by
+  // the 32 threads that share e... ) -- laid out so that lanes read contiguous addresses: lane = d
+  float M = -INFINITY;
+  for (int ch = lo + d; ch < hi; ch += 32) M = fmaxf(M, pm[(long long)ch * kHidden + e]);      // thread (d = chunk offset, e = column)
+  // reduce over the 32 `d` rows of the block for every column e through LDS
+  s_m[d][e] = M;
+  __syncthreads();
+  if (d == 0) {
+    float mm = s_m[0][e];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) mm = fmaxf(mm, s_m[k][e]);
+    s_M[e] = mm;
+  }
+  __syncthreads();
+  // S_r[col]: same chunk-strided scan, column = e
+  {
+    const float Mc = s_M[e];
+    float S = 0.f;
+    for (int ch = lo + d; ch < hi; ch += 32) S += ps[(long long)ch * kHidden + e] * expf(pm[(long long)ch * kHidden + e] - Mc);
+    __syncthreads();
+    s_m[d][e] = S;
+    __syncthreads();
+    if (d == 0) {
+      float ss = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) ss += s_m[k][e];
+      s_S[e] = ss;
+    }
+  }
+  __syncthreads();
+  // ctx_r[d][e]: thread (d, e) walks the chunks; the weights exp(m_c[d] - M_r[d]) of 64 chunks at a time come from LDS
+  const float Md = s_M[d];
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int base = lo; base < hi; base += 64) {
+    const int nb = min(64, hi - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * kDimHead; i += 1024) {
+      const int c = i >> 5, col = i & 31;
+      s_m[c][col] = expf(pm[(long long)(base + c) * kHidden + col] - s_M[col]);
+    }
+    __syncthreads();
+    int c = 0;
+    for (; c + 2 <= nb; c += 2) {
+      acc0 = fmaf(s_m[c][d], pc[(long long)(base + c) * kHeads * 1024], acc0);
+      acc1 = fmaf(s_m[c + 1][d], pc[(long long)(base + c + 1) * kHeads * 1024], acc1);
+    }
+    if (c < nb) acc0 = fmaf(s_m[c][d], pc[(long long)(base + c) * kHeads * 1024], acc0);
+  }
+  (void)Md;
+  const long long o = ((long long)blockIdx.x * gridDim.y + bh);
+  r_ctx[o * 1024 + d * kDimHead + e] = acc0 + acc1;
+  if (d == 0) { r_m[o * kDimHead + e] = s_M[e]; r_s[o * kDimHead + e] = s_S[e]; }
+}
+
+__global__ __launch_bounds__(1024) void attn_final_kernel(const float* __restrict__ r_ctx, const float* __restrict__ r_m,
+                                                          const float* __restrict__ r_s, int nrange, float* __restrict__ ctx,
+                                                          float* __restrict__ colM, float* __restrict__ colS, const float* __restrict__ wout,
+                                                          float* __restrict__ weff, int C, int bk, int f16, unsigned* range_flag) {
+  __shared__ float s_ctx[kDimHead][kDimHead + 1];
+  __shared__ float s_w[16][kDimHead + 1];          // exp(M_r - M) per range and column (nrange <= 16)
+  __shared__ float s_M[kDimHead], s_S[kDimHead];
+  // grid (B*heads, output-channel tiles of 128): every tile block re-derives the head's ctx (a few KB of range partials), tile 0 stores it
+  const int bh = blockIdx.x, b = bh / kHeads, h = bh % kHeads;
+  const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
+  const int nbh = gridDim.x;
+  const bool writer = blockIdx.y == 0;
+  if (d == 0) {
+    float M = -INFINITY;
+    for (int r = 0; r < nrange; ++r) M = fmaxf(M, r_m[((long long)r * nbh + bh) * kDimHead + e]);
+    float S = 0.f;
+    for (int r = 0; r < nrange; ++r) {
+      const float w = expf(r_m[((long long)r * nbh + bh) * kDimHead + e] - M);
+      s_w[r][e] = w;
+      S += r_s[((long long)r * nbh + bh) * kDimHead + e] * w;
+    }
+    s_M[e] = M; s_S[e] = S;
+    if (writer) {
+      colM[(long long)b * kHidden + h * kDimHead + e] = M;
+      colS[(long long)b * kHidden + h * kDimHead + e] = S;
+    }
+  }
+  __syncthreads();
+  float acc = 0.f;
+  for (int r = 0; r < nrange; ++r) acc = fmaf(s_w[r][d], r_ctx[((long long)r * nbh + bh) * 1024 + d * kDimHead + e], acc);
+  const float v = acc / s_S[d];
+  if (writer) ctx[((long long)b * kHeads + h) * 1024 + d * kDimHead + e] = v;
+  if (!weff) return;
+  s_ctx[d][e] = v;
+  __syncthreads();
+  // weff[co][h*32 + dd] = sum_e wout[co][h*32 + e] * ctx[dd][e]: thread t takes (co = tile * 128 + t / 32 + 32 k, dd = t % 32)
+  const int dd = threadIdx.x & 31;
+  bool over = false;
+  const int co_end = min(C, ((int)blockIdx.y + 1) * 128);
+  for (int co = blockIdx.y * 128 + (threadIdx.x >> 5); co < co_end; co += 32) {
+    const float* w = wout + (long long)co * kHidden + h * kDimHead;
+    float a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kDimHead; ++k) a2 = fmaf(w[k], s_ctx[dd][k], a2);
+    const int hd = h * kDimHead + dd;
+    const long long o = (long long)b * C * kHidden + ((long long)(hd / bk) * C + co) * bk;
+    if (!f16) {
+      weff[o + hd % bk] = a2;
+    } else {
+      _Float16* w16 = reinterpret_cast<_Float16*>(weff + o);
+      const int k = hd % 32;
+      us_half hh_, ll_;
+      split_f16x3(a2, hh_, ll_, over);
+      w16[(k / 8) * 16 + k % 8] = hh_;
+      w16[(k / 8) * 16 + 8 + k % 8] = ll_;
+    }
+  }
+  range_report(range_flag, over, kRangeWeight);
+}
+
+// scratch: (kAttnMaxSplit * B * heads) * (1024 + 64) floats
+hipError_t launch_attn_merge(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks, float* ctx, float* colM,
+                             float* colS, float* scratch, const float* wout, float* weff, int C, int bk, bool f16, hipStream_t s) {
+  if (f16 && bk != 32) return hipErrorInvalidValue;
+  int nrange = (nchunks + 63) / 64;
+  if (nrange > kAttnMaxSplit) nrange = kAttnMaxSplit;
+  if (nrange < 1) nrange = 1;
+  const int per_range = (nchunks + nrange - 1) / nrange;
+  nrange = (nchunks + per_range - 1) / per_range;
+  const long long nbh = (long long)B * kHeads;
+  float* r_ctx = scratch;
+  float* r_m = r_ctx + (long long)kAttnMaxSplit * nbh * 1024;
+  float* r_s = r_m + (long long)kAttnMaxSplit * nbh * kDimHead;
+  hipLaunchKernelGGL(attn_merge_kernel, dim3(nrange, (unsigned)nbh), dim3(1024), 0, s, part_ctx, part_m, part_s, nchunks, per_range, r_ctx, r_m, r_s);
+  hipLaunchKernelGGL(attn_final_kernel, dim3((unsigned)nbh, weff ? (unsigned)((C + 127) / 128) : 1u), dim3(1024), 0, s, r_ctx, r_m, r_s, nrange, ctx, colM, colS, wout, weff, C, bk,
+                     f16 ? 1 : 0, current_range_flag());
+  return hipGetLastError();
+}
+
 // weff[b] in the conv kernel's packed layout [1 tap][128/bk][C][bk]:
 //   weff[co][h*32+d] = sum_e wout[co][h*32+e] * ctx[b][h][d][e]
 __global__ __launch_bounds__(256) void attn_weff_kernel(const float* __restrict__ ctx, const float* __restrict__ wout,

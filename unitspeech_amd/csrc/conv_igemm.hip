@@ -985,6 +985,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         static int tm_pre = -1;
         if (tm_pre < 0) { const char* e = getenv("US_TM_PRESPLIT"); tm_pre = e ? atoi(e) : 0; }
         tm = tm_pre > 0 ? tm_pre : ((long long)a.Hs * a.Ws >= 512 ? 128 : 64);
+        static int tm_pre1 = -1;                     // 1x1 with a pre-split input (the folded to_out, K = 128): US_TM_PRESPLIT_1X1
+        if (tm_pre1 < 0) { const char* e = getenv("US_TM_PRESPLIT_1X1"); tm_pre1 = e ? atoi(e) : 64; }
+        if (a.ntaps == 1 && a.nphase <= 1) tm = tm_pre1;
       } else if (a.f16 == 1) {
         // Winograd-domain GEMMs (all items of a frequency in one M range): the largest tile that still fills the chip
         const long long per256 = (long long)((a.Hs * a.Ws + 255) / 256) * nt * a.B;

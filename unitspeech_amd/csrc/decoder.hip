@@ -388,7 +388,7 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false
   b.ctx = A.alloc<float>(B * kHeads * kDimHead * kDimHead);
   b.colM = A.alloc<float>(B * kHidden);
   b.colS = A.alloc<float>(B * kHidden);
-  b.ctx_split = A.alloc<float>((size_t)kAttnMaxSplit * B * kHeads * kDimHead * kDimHead);
+  b.ctx_split = A.alloc<float>(attn_merge_scratch_floats(Bp));
   b.splitk_floats = B * ((size_t)4 << 20);  // 4 Mi floats per item: the conv launcher's bound on its split-K slabs
   b.splitk = A.alloc<float>(b.splitk_floats);
   b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
@@ -720,6 +720,7 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   float* qkv = b.QKV[l];
   int q_ld = 3 * kHidden;
   bool q_split = false;
+  int nparts = nch;
   if (e.h->attn_fuse && at.qkv.w->qkv_rows.p) {
     // to_qkv with the n-reduction in its epilogue: only q is written ([n][128]); chunks of 64 rows (ConvArgs::attn_part_ctx)
     const int H = e.h->cfg.n_feats >> l, W = e.T >> l;
@@ -731,18 +732,21 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
     a.set_tap(0, 0, 0, 0);
     a.attn_part_ctx = b.part_ctx; a.attn_part_m = b.part_m; a.attn_part_s = b.part_s; a.attn_nchunks = nch64;
     // q has one reader, the folded to_out convolution below: where that runs as f16x3 it takes q pre-split
-    q_split = e.h->presplit && e.h->f16x3 && e.h->f16x3_direct && a.f16 == 2;
+    static int q_split_env = -1;                     // US_Q_SPLIT=0: q stays fp32 (A/B)
+    if (q_split_env < 0) { const char* ev = getenv("US_Q_SPLIT"); q_split_env = ev ? atoi(ev) : 0; }      // measured: -0.4 % (K = 128: not split-bound)
+    q_split = q_split_env && e.h->presplit && e.h->f16x3 && e.h->f16x3_direct && a.f16 == 2;
     a.out_split = q_split ? 1 : 0;
     CK(run_conv(e, a));
-    CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch64, b.ctx, b.colM, b.colS, b.ctx_split, e.s));
+    nparts = nch64;
   } else {
     CK(conv1x1(e, at.qkv, in, in_ld, l, false, qkv, 3 * kHidden, nullptr, 0, nullptr, nullptr, 0, nullptr));
     CK(launch_attn_ctx_partial(qkv, e.Bp, n, b.part_ctx, b.part_m, b.part_s, nch, e.s));
-    CK(launch_attn_ctx_finalize(b.part_ctx, b.part_m, b.part_s, e.Bp, nch, b.ctx, b.colM, b.colS, b.ctx_split, e.s));
   }
   const int bk = pick_bk(kHidden);
   const bool f16 = e.h->f16x3 && e.h->f16x3_direct;
-  CK(launch_attn_weff(b.ctx, at.out_w->buf.p, b.weff, e.Bp, at.dim, bk, e.s, f16));
+  // chunk partials -> ctx (+ the softmax statistics) -> W_eff = W_out blockdiag(ctx^T), two launches
+  CK(launch_attn_merge(b.part_ctx, b.part_m, b.part_s, e.Bp, nparts, b.ctx, b.colM, b.colS, b.ctx_split, at.out_w->buf.p, b.weff, at.dim, bk,
+                       f16, e.s));
   ConvW eff;
   eff.cin = kHidden; eff.cout = at.dim;
   Slot tmp;             // only .bk / .buf / .direct_f16 are read by base_args
@@ -834,7 +838,8 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
       const ResnetW& r = d.r1;
       double* st1 = next_stats(e);
       double* st2 = next_stats(e);
-      CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], b.Q[0], st1, e.Bp, F, T, c, e.s));
+      // (the block's 1x1 res_conv output is not stored: its GroupNorm pass below re-evaluates it from the two input channels)
+      CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], nullptr, st1, e.Bp, F, T, c, e.s));
       if (r.c2.w->wino.p && b.wino_v && h->wino_fuse_gn && gn_wino_input_supported(c)) {
         WinoGnArgs g;       // as in resnet(): block1's GroupNorm + Mish + time embedding inside block2's input transform
         g.stats = st1; g.gamma = r.g1->buf.p; g.beta = r.b1->buf.p; g.temb = b.tproj + b.tproj_off[r.index];
@@ -849,7 +854,17 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
           CK(conv3x3(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2));
         }
       }
-      CK(gn_apply(e, b.S2[0], 0, c, st2, r.g2, r.b2, nullptr, b.Q[0], c, false, true, b.P[0], c));
+      {
+        GnApplyArgs ga;
+        memset(&ga, 0, sizeof ga);
+        ga.y = b.S2[0]; ga.y_ld = c; ga.stats = st2; ga.gamma = r.g2->buf.p; ga.beta = r.b2->buf.p;
+        ga.mask = e.mask; ga.mask_ld = e.T; ga.mask_step = 1; ga.mask_bmod = e.Bm;
+        ga.res2_in = b.in2; ga.res2_w = r.res.w->buf.p; ga.res2_b = r.res.b->buf.p;
+        ga.post_mask = 1;
+        ga.out = b.P[0]; ga.out_ld = c;
+        ga.B = e.Bp; ga.H = F; ga.W = T; ga.C = c;
+        CK(launch_gn_apply(ga, e.s));
+      }
     } else {
       CK(resnet(e, d.r1, cur, cur_ld, b.P[l], c, true));
     }

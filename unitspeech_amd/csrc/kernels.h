@@ -196,6 +196,8 @@ struct GnApplyArgs {
   const float* mask; int mask_ld, mask_step, mask_bmod;   // frame mask, column w reads mask[w*mask_step]
   const float* temb; int temb_ld;                          // optional [B][temb_ld] per-channel addend
   const float* res; int res_ld; int res_masked;            // optional residual (times mask when res_masked)
+  const float* res2_in; const float* res2_w; const float* res2_b;   // or (res == null): residual = Conv2d(2, C, 1) of the stacked input
+                                                           // [B][H*W][2], weight [C][2], bias [C] (the first ResnetBlock's res_conv)
   int post_mask;
   unsigned* range_flag;                                    // set by the launcher; out_split reports here
   int out_split;                                           // out receives the two-plane fp16 form (per 8 channels: 8 hi | 8 lo, same bytes
@@ -223,6 +225,11 @@ hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, 
 // f16 = true (bk = 32): weff as two interleaved fp16 planes per value, for the f16x3 form of the folded to_out convolution
 hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s,
                             bool f16 = false);
+// The same merge in two launches (ranges of chunks with their own maxima, then the ranges), with the fold of ctx into to_out's weights
+// (launch_attn_weff) done by the second one when weff != null.  scratch: attn_merge_scratch_floats(B) floats.
+inline size_t attn_merge_scratch_floats(int B) { return (size_t)kAttnMaxSplit * B * kHeads * (kDimHead * kDimHead + 2 * kDimHead); }
+hipError_t launch_attn_merge(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks, float* ctx, float* colM,
+                             float* colS, float* scratch, const float* wout, float* weff, int C, int bk, bool f16, hipStream_t s);
 inline int attn_nchunks(int n) { return (n + 127) / 128; }
 
 // ---- small dense layers ----------------------------------------------------------------------------

@@ -88,13 +88,18 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
     patch[yy][xx][c] = v;
   }
   __syncthreads();
-  for (int co = tid; co < C; co += 256) {   // (all 256 threads active when C >= 256; C=128 uses half)
+  // thread = (output channel, slice of the 32 frames): with C = 128 the two halves of the block take 16 frames each (one thread per
+  // channel left half the block idle: 87 us of the 7.5 ms evaluation at 80 x 1024)
+  const int nsub = (C <= 128 && 256 % C == 0) ? 256 / C : 1;
+  const int sub = nsub > 1 ? tid / C : 0;
+  const int xlo = sub * (FC_TW / nsub), xhi = xlo + FC_TW / nsub;
+  for (int co = nsub > 1 ? tid % C : tid; co < C; co += 256) {
     float w[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) w[i] = w3[co * 18 + i];   // OIHW: [co][ci][ky][kx]
     const float bb = b3[co], r0 = w1[co * 2], r1 = w1[co * 2 + 1], rb = b1[co];
     float s1 = 0.f, s2 = 0.f;
-    for (int xx = 0; xx < FC_TW; ++xx) {
+    for (int xx = xlo; xx < xhi; ++xx) {
       if (t0 + xx >= T) break;
       float acc = bb;
 #pragma unroll
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
       y[p * C + co] = acc;
       s1 += acc;
       s2 += acc * acc;
-      r[p * C + co] = fmaf(r1, patch[1][xx + 1][1], fmaf(r0, patch[1][xx + 1][0], rb));
+      if (r) r[p * C + co] = fmaf(r1, patch[1][xx + 1][1], fmaf(r0, patch[1][xx + 1][0], rb));
     }
     if (stats) {
       atomicAdd(&gred[co / (C / kGroups)][0], (double)s1);
@@ -202,7 +207,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
   bool over = false;
   int c = (int)(i % C4) * 4;
   f32x4 sc, sh, te = {0.f, 0.f, 0.f, 0.f};
+  // res2: the residual is the 2-channel 1x1 res_conv of the first ResnetBlock, evaluated here from the stacked input (2 floats per pixel)
+  // exactly as first_conv_kernel would have stored it (same fmaf chain): 126 MB less written and read per item at 80 x 1024
+  f32x4 r2w0 = {0.f, 0.f, 0.f, 0.f}, r2w1 = r2w0, r2b = r2w0;
+  const float* in2b = a.res2_in ? a.res2_in + (long long)b * n * 2 : nullptr;
   auto load_quad = [&](int cc) {
+    if (in2b) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r2w0[k] = a.res2_w[(cc + k) * 2]; r2w1[k] = a.res2_w[(cc + k) * 2 + 1]; }
+      r2b = *reinterpret_cast<const f32x4*>(a.res2_b + cc);
+    }
     f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + cc);
     f32x4 be = *reinterpret_cast<const f32x4*>(a.beta + cc);
 #pragma unroll
@@ -233,6 +247,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
     o += te;
     if (rb) {
       f32x4 rr = *reinterpret_cast<const f32x4*>(rb + p * a.res_ld + c);
+      o += a.res_masked ? rr * m : rr;
+    } else if (in2b) {
+      const float2 x2 = *reinterpret_cast<const float2*>(in2b + p * 2);
+      f32x4 rr;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rr[k] = fmaf(r2w1[k], x2.y, fmaf(r2w0[k], x2.x, r2b[k]));
       o += a.res_masked ? rr * m : rr;
     }
     if (a.post_mask) o *= m;
