@@ -58,3 +58,18 @@ def test_frontend_bench_runs():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["finite"] and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port"
     assert d["max_abs_diff_vs_oracle"] <= 2e-5
+
+
+def test_finetune_loss_trajectory_of_three_iterations_vs_oracle():
+    """BASELINE configs[3] beyond one iteration: bench_finetune.py --check 3 replays the first three fine-tune iterations (crop, t, z, forward,
+    backward, clip, Adam: finetune.py:131-165) on the CPU oracle under torch autograd with the same draws; the losses of iterations 2 and
+    3 depend on the weights the earlier updates produced, so agreement pins the whole loop, optimiser included."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_finetune.py"), "--iters", "3", "--warmup", "3", "--check", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    got, ref = d["first_losses"], d["oracle_losses"]
+    assert len(got) == 3 and len(ref) == 3 and len(set(got)) == 3
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (got, ref)

@@ -49,6 +49,7 @@ struct Slot {
   bool is_qkv = false;     // attention to_qkv: a second forward pack with the rows in qkv_src_row() order (ConvArgs::attn_part_ctx)
   DevBuf qkv_rows;         // ... in the same operand form as `buf` (f16x3 planes or fp32)
   float* grad = nullptr; // caller-owned gradient buffer (reference layout) for the current backward call
+  bool grad_unscaled = false;   // ... already multiplied by the inverse loss scale by the pass that wrote it (conv_wgrad's unpack)
   bool loaded = false;
 };
 

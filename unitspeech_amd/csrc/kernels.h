@@ -305,7 +305,8 @@ hipError_t launch_wgrad_amax(const float* g, int ld, long long rows, int C, floa
 // true when launch_wgrad(a) gives every gw element exactly one writing workgroup (LDS kernel, one pixel chunk per item, one item
 // or per-item gw): the caller may then skip zeroing gw and set a.overwrite
 bool launch_wgrad_single_writer(const WgradArgs& a);
-hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s);
+// scale (optional device scalar): dst = unpacked src * scale[0]
+hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s, const float* scale = nullptr);
 hipError_t launch_pack_dgrad_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, bool oihw, int bk, hipStream_t s);
 hipError_t launch_colsum(const float* g, int ld, long long rows, int C, const float* scale, float* out, hipStream_t s);
 hipError_t launch_rowsum_per_item(const float* g, int ld, int B, long long n, int C, float* out, hipStream_t s);

@@ -486,7 +486,9 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
 }
 
 // packed [KH*KW][Cout][Cin] -> reference layout (Conv2d [Cout][Cin][KH][KW] or ConvTranspose2d [Cin][Cout][KH][KW])
-__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int taps, int oihw) {
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int taps, int oihw,
+                                    const float* __restrict__ scale) {
+  const float k = scale ? scale[0] : 1.f;          // the inverse of the backward pass's loss scale (a power of two: exact)
   const long long total = (long long)taps * Cout * Cin;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     int t = (int)(i % taps);
@@ -494,15 +496,15 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
     int c2 = (int)(r % (oihw ? Cin : Cout));
     int c1 = (int)(r / (oihw ? Cin : Cout));
     int co = oihw ? c1 : c2, ci = oihw ? c2 : c1;
-    dst[i] = src[((long long)t * Cout + co) * Cin + ci];
+    dst[i] = src[((long long)t * Cout + co) * Cin + ci] * k;
   }
 }
 
-hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s) {
+hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s, const float* scale) {
   long long total = (long long)taps * Cout * Cin;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, taps, oihw ? 1 : 0);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, s, src, dst, Cout, Cin, taps, oihw ? 1 : 0, scale);
   return hipGetLastError();
 }
 
