@@ -73,9 +73,10 @@ int us_range_status_async(us_handle h, unsigned* status_host, int reset, us_stre
 int us_decoder_load_weight(us_handle h, const char* key, const float* data, const int64_t* shape, int ndim,
                            us_stream stream);
 /* Completes a batch of us_decoder_load_weight calls: tensors the library keeps in the reference's own layout (biases,
- * GroupNorm affine, MLP weights, the unconditional embeddings) are copied by ONE table-driven launch enqueued here, so their
- * `data` pointers must stay valid until this call has been made on the same stream.  Every computing entry point refuses to
- * run (US_EWEIGHTS) while loads are pending. */
+ * GroupNorm affine, MLP weights, the unconditional embeddings) are copied, and the split-precision packs of the convolution
+ * weights are written, by ONE table-driven launch each, enqueued here: every `data` pointer handed to us_decoder_load_weight
+ * must stay valid until this call has been made on the same stream.  Every computing entry point refuses to run (US_EWEIGHTS)
+ * while loads are pending. */
 int us_decoder_flush_weights(us_handle h, us_stream stream);
 /* Number of state_dict tensors the configured architecture has / that have been loaded so far. */
 int us_decoder_num_weights(us_handle h);

@@ -25,6 +25,7 @@
 // BOTH operands, so the pairs (j, 4+j) are summed by instruction j; the K-sum is complete, only its order differs.
 #include <type_traits>
 #include "kernels.h"
+#include "pack_f16.h"
 
 namespace us {
 
@@ -480,6 +481,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   };
 
   if (NSTG == 3) {
+    // static priority for the second-dispatched half of an 8-wave workgroup (the arbitration loser of every segment); experiment bit
+    if (NW == 8 && (a.debug & 512) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     // chunk s lives in buffer s % 3.  At step s: wait for this wave's pieces of chunk s (chunk s+1 may stay in flight), barrier
     // (everybody's pieces have landed, and everybody is done reading chunk s-1, whose buffer chunk s+2 is about to overwrite),
     // issue chunk s+2, multiply chunk s.
@@ -1089,12 +1092,6 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
 }
 
 // ---- weight repack --------------------------------------------------------------------------------
-__device__ __forceinline__ int qkv_src_row_dev(int cp) {       // == qkv_src_row (kernels.h)
-  if (cp < kHidden) return cp;
-  const int t = cp - kHidden, h = t >> 6, w = t & 63;
-  return (w < kDimHead ? kHidden : 2 * kHidden) + h * kDimHead + (w & (kDimHead - 1));
-}
-
 __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int KH, int KW,
                                         int oihw, int bk, int qkv_rows) {
   const long long total = (long long)KH * KW * Cout * Cin;
@@ -1114,36 +1111,11 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ src, float* __
   }
 }
 
-// f16x3 form (bk = 32): dst (halves) [tap][Cin/32][Cout][4 groups x (8 hi | 8 lo)], same bytes and row structure as the fp32 pack.
-// One thread = one 32-byte piece (8 input channels of one (tap, output channel)): two 16-byte stores.
-typedef _Float16 half8p __attribute__((ext_vector_type(8)));
+// f16x3 form (bk = 32): body in pack_f16.h (shared with the table-driven launch of wino.hip)
 __global__ __launch_bounds__(256) void pack_conv_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin,
                                                                    int KH, int KW, int oihw, unsigned* range_flag, int qkv_rows) {
   bool over = false;
-  const long long total = (long long)KH * KW * Cout * (Cin / 8);
-  const int nchunk = Cin / 32;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int g4 = (int)(i & 3);
-    long long t = i >> 2;
-    int co = (int)(t % Cout); t /= Cout;
-    if (qkv_rows) co = qkv_src_row_dev(co);
-    const int ch = (int)(t % nchunk);
-    const int tap = (int)(t / nchunk);
-    const int ky = tap / KW, kx = tap % KW;
-    half8p hi, lo;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int ci = ch * 32 + g4 * 8 + kk;
-      const long long si = oihw ? (((long long)co * Cin + ci) * KH + ky) * KW + kx : (((long long)ci * Cout + co) * KH + ky) * KW + kx;
-      us_half h, l;
-      split_f16x3(src[si], h, l, over);
-      hi[kk] = h;
-      lo[kk] = l;
-    }
-    _Float16* d = dst + i * 16;
-    *reinterpret_cast<half8p*>(d) = hi;
-    *reinterpret_cast<half8p*>(d + 8) = lo;
-  }
+  conv_pack_f16_body(src, dst, Cout, Cin, KH, KW, oihw, qkv_rows, blockIdx.x, gridDim.x, over);
   range_report(range_flag, over, kRangeWeight);
 }
 

@@ -15,6 +15,7 @@
 
 #include "../../include/unitspeech_hip.h"
 #include "kernels.h"
+#include "pack_f16.h"
 
 using namespace us;
 
@@ -129,9 +130,13 @@ struct us_decoder {
   // RAW tensors (biases, GroupNorm affine, MLP weights: ~130 small ones) are copied by ONE table-driven launch per weight sync
   // instead of one hipMemcpyAsync each (fine-tuning re-loads every tensor after every optimiser step)
   std::vector<CopyEnt> pending_copies;
+  // ... and the f16x3 packs of the convolution weights (forward and data-gradient forms) by ONE table-driven launch (pack_f16.h)
+  std::vector<PackJob> pending_packs;
+  PackJob* pack_tab_dev = nullptr;
+  static constexpr size_t kStageBytes = 64 << 10;      // one staging buffer holds either table
   CopyEnt* copy_tab_dev = nullptr;
   CopyEnt* copy_tab_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring
-  static constexpr int kCaptureTabs = 16;
+  static constexpr int kCaptureTabs = 32;
   CopyEnt* copy_tab_capture[kCaptureTabs] = {};    // write-once staging for uploads recorded into a HIP graph (no allocation is legal
   int copy_tab_capture_used = 0;                    // while a stream captures): one per captured weight sync
   hipEvent_t copy_tab_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -963,8 +968,14 @@ inline hipError_t compute_time_block(EvalCtx& e, TimeBlock& tb, const float* coe
 #include "train_host.inc"
 
 // ents[0..n) -> dev through the pinned staging ring (or a write-once table of its own while the stream is being captured)
+int upload_bytes(us_decoder* h, const void* src, size_t nbytes, void* dev, hipStream_t st);
 int upload_table(us_decoder* h, const CopyEnt* ents, size_t n, CopyEnt* dev, hipStream_t st) {
   if (n > h->copy_tab_cap) return h->fail(US_EINVAL, "internal: copy table overflow");
+  return upload_bytes(h, ents, n * sizeof(CopyEnt), dev, st);
+}
+int upload_bytes(us_decoder* h, const void* ents, size_t nbytes, void* dev, hipStream_t st) {
+  if (nbytes > us_decoder::kStageBytes) return h->fail(US_EINVAL, "internal: staging table overflow");
+  const size_t n = nbytes;
   const int slot = h->copy_tab_i++ & 3;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
@@ -977,8 +988,8 @@ int upload_table(us_decoder* h, const CopyEnt* ents, size_t n, CopyEnt* dev, hip
   } else if (h->copy_tab_ev[slot]) {
     (void)hipEventSynchronize(h->copy_tab_ev[slot]);      // the upload that last used this staging slot has completed
   }
-  memcpy(host, ents, n * sizeof(CopyEnt));
-  US_HIP(h, hipMemcpyAsync(dev, host, n * sizeof(CopyEnt), hipMemcpyHostToDevice, st));
+  memcpy(host, ents, n);
+  US_HIP(h, hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, st));
   if (cap == hipStreamCaptureStatusNone) {
     if (!h->copy_tab_ev[slot]) US_HIP(h, hipEventCreateWithFlags(&h->copy_tab_ev[slot], hipEventDisableTiming));
     US_HIP(h, hipEventRecord(h->copy_tab_ev[slot], st));
@@ -986,7 +997,22 @@ int upload_table(us_decoder* h, const CopyEnt* ents, size_t n, CopyEnt* dev, hip
   return US_OK;
 }
 
+int flush_packs(us_decoder* h, hipStream_t st) {
+  const size_t n = h->pending_packs.size();
+  if (n == 0) return US_OK;
+  int total = 0;
+  for (auto& j : h->pending_packs) { j.blk0 = total; j.nblk = pack_job_blocks(j); total += j.nblk; }
+  int rc = upload_bytes(h, h->pending_packs.data(), n * sizeof(PackJob), h->pack_tab_dev, st);
+  if (rc) return rc;
+  RangeScope range_scope(h->range_flag);
+  US_HIP(h, launch_pack_table(h->pack_tab_dev, (int)n, total, st));
+  h->pending_packs.clear();
+  return US_OK;
+}
+
 int flush_copies(us_decoder* h, hipStream_t st) {
+  int rcp = flush_packs(h, st);
+  if (rcp) return rcp;
   const size_t n = h->pending_copies.size();
   if (n == 0) return US_OK;
   int rc = upload_table(h, h->pending_copies.data(), n, h->copy_tab_dev, st);
@@ -999,7 +1025,7 @@ int flush_copies(us_decoder* h, hipStream_t st) {
 int check_ready(us_decoder* h) {
   for (auto& s : h->slots)
     if (!s->loaded) return h->fail(US_EWEIGHTS, "weight '%s' has not been loaded", s->key.c_str());
-  if (!h->pending_copies.empty())
+  if (!h->pending_copies.empty() || !h->pending_packs.empty())
     return h->fail(US_EWEIGHTS, "us_decoder_load_weight calls have not been followed by us_decoder_flush_weights");
   return US_OK;
 }
@@ -1114,12 +1140,17 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
     }
   }
   h->copy_tab_cap = h->slots.size() + 8;      // (+ the input gradients of a backward's table)
-  bool tab_ok = hipMalloc(reinterpret_cast<void**>(&h->copy_tab_dev), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess &&
-                hipMalloc(reinterpret_cast<void**>(&h->grad_tab_dev), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
+  if (h->copy_tab_cap * sizeof(CopyEnt) > us_decoder::kStageBytes || 3 * h->slots.size() * sizeof(PackJob) > us_decoder::kStageBytes) {
+    g_last_error = "architecture too large for the weight-table staging buffers";
+    return US_EINVAL;
+  }
+  bool tab_ok = hipMalloc(reinterpret_cast<void**>(&h->copy_tab_dev), us_decoder::kStageBytes) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void**>(&h->grad_tab_dev), us_decoder::kStageBytes) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void**>(&h->pack_tab_dev), us_decoder::kStageBytes) == hipSuccess;
   for (int i = 0; i < 4 && tab_ok; ++i)
-    tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_host[i]), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
+    tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_host[i]), us_decoder::kStageBytes) == hipSuccess;
   for (int i = 0; i < us_decoder::kCaptureTabs && tab_ok; ++i)
-    tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_capture[i]), h->copy_tab_cap * sizeof(CopyEnt)) == hipSuccess;
+    tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_capture[i]), us_decoder::kStageBytes) == hipSuccess;
   if (!tab_ok) { g_last_error = "allocation of the weight-copy table failed"; return US_EHIP; }
   *out = h.release();
   return US_OK;
@@ -1136,6 +1167,7 @@ int us_decoder_destroy(us_handle h) {
   if (h->zeros) (void)hipFree(h->zeros);
   if (h->copy_tab_dev) (void)hipFree(h->copy_tab_dev);
   if (h->grad_tab_dev) (void)hipFree(h->grad_tab_dev);
+  if (h->pack_tab_dev) (void)hipFree(h->pack_tab_dev);
   if (h->range_flag) (void)hipFree(h->range_flag);
   if (h->range_host) (void)hipHostFree(h->range_host);
   if (h->grad_scale) (void)hipFree(h->grad_scale);
@@ -1169,6 +1201,18 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
     if (shape[i] != s->shape[i]) return h->fail(US_ESHAPE, "'%s': dim %d is %lld, expected %lld", key, i, (long long)shape[i], (long long)s->shape[i]);
   hipStream_t st = static_cast<hipStream_t>(stream);
   RangeScope range_scope(h->range_flag);      // the f16x3 packs report a weight beyond the fp16 range
+  // f16x3 packs are deferred like the RAW copies: one table-driven launch at us_decoder_flush_weights (`data` must stay valid until then)
+  auto defer = [&](PackJob j) {
+    for (auto& p : h->pending_packs)
+      if (p.dst == j.dst) { p = j; return; }      // re-loaded before the flush: the later source wins
+    h->pending_packs.push_back(j);
+  };
+  auto wino_f16 = [&](float* dst, bool dgrad) {
+    defer(PackJob{data, reinterpret_cast<_Float16*>(dst), 0, (int)s->shape[0], (int)s->shape[1], 3, 3, dgrad ? 1 : 0, 0, 0, 0});
+  };
+  auto conv_f16 = [&](float* dst, int Cout, int Cin, int KH, int KW, bool oihw, bool qkv_rows = false) {
+    defer(PackJob{data, reinterpret_cast<_Float16*>(dst), 1, Cout, Cin, KH, KW, oihw ? 1 : 0, qkv_rows ? 1 : 0, 0, 0});
+  };
   switch (s->kind) {
     case Kind::RAW:
       // deferred: one table-driven launch for all RAW tensors at the next us_decoder_flush_weights / computing entry point.  `data`
@@ -1182,28 +1226,28 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
       // data-gradient packs: GEMM-K = output channels, GEMM-N = input channels.  f16x3: the forward pack routine with the channel
       // roles swapped (an OIHW tensor read as "IOHW" with I = its O)
       if (s->dg_as_1x1 && s->dg_f16)
-        US_HIP(h, launch_pack_conv_weight_f16(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], 1, 1, false, st));
+        conv_f16(s->dg.p, (int)s->shape[1], (int)s->shape[0], 1, 1, false);
       else if (s->dg_as_1x1)
         US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk_dg, st));
       break;
     case Kind::CONV_OIHW:
       // a conv that runs in the Winograd domain never reads its direct-form pack (conv3x3 takes the Winograd branch whenever
       // wino.p is set; every workspace plan of this handle then has the V/M scratch)
-      if (s->wino.p && s->wino_f16) US_HIP(h, launch_wino_pack_weight_f16(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], st));
+      if (s->wino.p && s->wino_f16) wino_f16(s->wino.p, false);
       else if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
-      else if (s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, st));
+      else if (s->direct_f16) conv_f16(s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true);
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
-      if (s->qkv_rows.p && s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->qkv_rows.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, st, true));
+      if (s->qkv_rows.p && s->direct_f16) conv_f16(s->qkv_rows.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, true);
       else if (s->qkv_rows.p) US_HIP(h, launch_pack_conv_weight(data, s->qkv_rows.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk, st, true));
-      if (s->wino_dg.p && s->wino_dg_f16) US_HIP(h, launch_wino_pack_weight_f16(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], st, true));
+      if (s->wino_dg.p && s->wino_dg_f16) wino_f16(s->wino_dg.p, true);
       else if (s->wino_dg.p) US_HIP(h, launch_wino_pack_weight(data, s->wino_dg.p, (int)s->shape[0], (int)s->shape[1], s->bk_dg, st, true));
-      else if (s->dg_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, st));
+      else if (s->dg_f16) conv_f16(s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false);
       else US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk_dg, st));
       break;
     case Kind::CONVT_IOHW:
-      if (s->direct_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, st));
+      if (s->direct_f16) conv_f16(s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false);
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk, st));
-      if (s->dg_f16) US_HIP(h, launch_pack_conv_weight_f16(data, s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, st));
+      if (s->dg_f16) conv_f16(s->dg.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true);
       else US_HIP(h, launch_pack_dgrad_weight(data, s->dg.p, (int)s->shape[1], (int)s->shape[0], (int)s->shape[2], (int)s->shape[3], false, s->bk_dg, st));
       break;
   }

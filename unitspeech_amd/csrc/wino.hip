@@ -5,6 +5,7 @@
 // The 16 element-wise products summed over Cin are 16 GEMMs, executed by conv_igemm_kernel.  All transforms are exact
 // up to fp32 rounding of sums of at most 4 terms with coefficients in {0, +-1, +-1/2}.
 #include "kernels.h"
+#include "pack_f16.h"
 
 namespace us {
 
@@ -367,55 +368,31 @@ __global__ void wino_pack_weight_kernel(const float* __restrict__ src, float* __
 // every frequency one whole 32-byte (8 hi | 8 lo) piece: 16-byte stores, neighbouring threads fill neighbouring pieces of a row
 // (fine-tuning re-packs every weight after every optimiser step: the element-wise 2-byte scatter of the first version took 2.1 of
 // an iteration's 14 ms).
-typedef _Float16 half8w __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void wino_pack_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int Cout, int Cin,
                                                                    int dgrad, unsigned* range_flag) {
   bool over = false;
-  const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-  const long long total = (long long)(K / 8) * N;          // thread = (k group of 8, n), k group fastest within a 32-channel row
-  const long long fstride = (long long)K * N * 2;          // halves per frequency
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int g4 = (int)(i & 3);                            // group of 8 inside the 32-channel chunk
-    const long long rn = i >> 2;                            // (k / 32) * N + n
-    const int n = (int)(rn % N), kc = (int)(rn / N);
-    const int k0 = kc * 32 + g4 * 8;
-    half8w hi[16], lo[16];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int k = k0 + kk;
-      const int co = dgrad ? k : n, ci = dgrad ? n : k;
-      const float* gs = src + ((long long)co * Cin + ci) * 9;
-      float g[9];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) g[t] = dgrad ? gs[8 - t] : gs[t];
-      float gg[4][3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        gg[0][q] = g[q];
-        gg[1][q] = 0.5f * (g[q] + g[3 + q] + g[6 + q]);
-        gg[2][q] = 0.5f * (g[q] - g[3 + q] + g[6 + q]);
-        gg[3][q] = g[6 + q];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float u[4] = {gg[r][0], 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]), 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]), gg[r][2]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          us_half h, l;
-          split_f16x3(u[q], h, l, over);
-          hi[r * 4 + q][kk] = h;
-          lo[r * 4 + q][kk] = l;
-        }
-      }
-    }
-    _Float16* d = dst + (rn * 32 + g4 * 8) * 2;
-#pragma unroll
-    for (int f = 0; f < 16; ++f) {
-      *reinterpret_cast<half8w*>(d + f * fstride) = hi[f];
-      *reinterpret_cast<half8w*>(d + f * fstride + 8) = lo[f];
-    }
-  }
+  wino_pack_f16_body(src, dst, Cout, Cin, dgrad, blockIdx.x, gridDim.x, over);      // pack_f16.h
   range_report(range_flag, over, kRangeWeight);
+}
+
+// every pending f16x3 pack of a weight sync in ONE launch: a block finds its job by bisection over the jobs' first-block indices
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restrict__ jobs, int n_jobs, unsigned* range_flag) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= jobs[mid].blk0) lo = mid; else hi = mid - 1;
+  }
+  const PackJob j = jobs[lo];
+  bool over = false;
+  if (j.kind == 0) wino_pack_f16_body(j.src, j.dst, j.Cout, j.Cin, j.a, (long long)blockIdx.x - j.blk0, j.nblk, over);
+  else conv_pack_f16_body(j.src, j.dst, j.Cout, j.Cin, j.KH, j.KW, j.a, j.b, (long long)blockIdx.x - j.blk0, j.nblk, over);
+  range_report(range_flag, over, kRangeWeight);
+}
+
+hipError_t launch_pack_table(const PackJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s) {
+  if (n_jobs <= 0 || total_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_table_kernel, dim3(total_blocks), dim3(256), 0, s, jobs_dev, n_jobs, current_range_flag());
+  return hipGetLastError();
 }
 
 hipError_t launch_wino_pack_weight_f16(const float* src, float* dst, int Cout, int Cin, hipStream_t s, bool dgrad) {
