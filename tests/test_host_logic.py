@@ -87,3 +87,71 @@ def test_f16x3_split_gemm_is_at_fp32_accuracy():
     x = np.random.default_rng(1).standard_normal(10000).astype(np.float32) * 100
     hi, lo = m.split16(x)
     assert np.abs((hi.astype(np.float64) + lo.astype(np.float64) / 2048) - x).max() <= np.abs(x).max() * 2.0 ** -22
+
+
+# ---- round 3: the range fall-back of the mirror and the bench's self-description, without a GPU -------------------------------------
+class _FakeEngine:
+    def __init__(self, exact, status=0):
+        self.exact, self._status, self.status_reads = exact, status, 0
+
+    def range_status(self, reset=True):
+        self.status_reads += 1
+        st, self._status = self._status, 0 if reset else self._status
+        return st
+
+
+def test_run_checked_repeats_a_flagged_inference_call_on_the_exact_engine(monkeypatch):
+    """`_run_checked` (unitspeech_amd/unitspeech.py): a clean status returns the default engine's result; a range event warns and
+    returns the exact engine's; an exact engine is never asked for its status; `range_check=False` skips the read."""
+    import warnings
+    from unitspeech_amd import unitspeech as US
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    runs = []
+
+    def run(e):
+        runs.append(e)
+        return ("exact" if e.exact else "fast")
+
+    fast, exact = _FakeEngine(False, 0), _FakeEngine(True)
+    assert US._run_checked(fast, run, lambda: exact, True, "t") == "fast" and runs == [fast] and fast.status_reads == 1
+    runs.clear()
+    fast = _FakeEngine(False, 1)
+    with pytest.warns(RuntimeWarning, match="exact-fp32"):
+        assert US._run_checked(fast, run, lambda: exact, True, "t") == "exact"
+    assert runs == [fast, exact]
+    runs.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert US._run_checked(exact, run, lambda: exact, True, "t") == "exact" and exact.status_reads == 0
+        fast = _FakeEngine(False, 1)
+        assert US._run_checked(fast, run, lambda: exact, False, "t") == "fast" and fast.status_reads == 0     # check switched off
+
+
+def test_model_exposes_exact_and_range_check_switches(monkeypatch):
+    monkeypatch.setenv("UNITSPEECH_EXACT", "1")
+    m = UnitSpeech(80, 16, [1, 2], 0.05, 20.0, 1000, 8)
+    assert m.exact is True and m.range_check is True and m.estimator._flags() == (True, True)
+    monkeypatch.delenv("UNITSPEECH_EXACT")
+    m = UnitSpeech(80, 16, [1, 2], 0.05, 20.0, 1000, 8)
+    assert m.exact is False and m.range_status() == 0            # no engine yet: nothing to report
+    m.exact = True
+    assert m.estimator._flags() == (True, True)
+
+
+def test_fine_tune_segment_refuses_lengths_beyond_the_mel(monkeypatch):
+    """an inconsistent y_lengths must raise before the kernel sees it (the reference's slicing would raise a shape error)."""
+    m = UnitSpeech(80, 16, [1, 2], 0.05, 20.0, 1000, 8)
+    y = torch.zeros(1, 80, 40)
+    with pytest.raises(ValueError, match="y_lengths"):
+        m.fine_tune_segment(torch.zeros(1, 80, 10), y, torch.LongTensor([41]), torch.zeros(1, 10, 40), 16, 80)
+    with pytest.raises(ValueError, match="y_lengths"):
+        m.fine_tune_segment(torch.zeros(1, 80, 10), y, torch.LongTensor([0]), torch.zeros(1, 10, 40), 16, 80)
+
+
+def test_bench_algorithmic_bytes_and_single_rank_census():
+    import bench
+    n = sum(int(np.prod(s)) for s in param_shapes(FULL).values())
+    assert n == 119145177
+    assert bench.algorithmic_bytes_per_eval(n, 3, 1024) == 4.0 * n + 3 * 1024 * 964.0          # SURVEY 8(d): weights once + B' T 964 B
+    world, ranks = bench.rank_census(None, 0, 1, torch.device("cpu"), "nccl")
+    assert world == 1 and ranks[0]["rank"] == 0

@@ -499,6 +499,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       US_STAMP_AT(st_t1);
       st_wait += st_t1 - st_t0;
 #endif
+#ifdef US_CONV_ABLATE
+      if (!(a.debug & 1024))       // timing ablation: no barrier in the three-buffer loop (races: results are wrong)
+#endif
       __builtin_amdgcn_s_barrier();
 #ifdef US_STAMP
       US_STAMP_AT(st_t2);
