@@ -115,6 +115,7 @@ struct us_decoder {
   bool presplit = true;      // US_PRESPLIT=0: block1's GroupNorm output stays fp32 for the direct block2 convolution (split in the kernel)
   bool attn_fuse = true;     // US_ATTN_FUSE=0: to_qkv writes q | k | v and attn_ctx_partial_kernel re-reads k, v (the training path's form)
   bool xcd_z = true;         // US_XCD_Z=0: the Winograd-domain GEMMs dealt to the XCDs by tile only, not by whole frequencies (A/B)
+  bool fuse_final = true;    // US_FUSE_FINAL=0: the final Block's GroupNorm + Mish as its own launch before the 1x1 projection
   bool wino_narrow = false; // US_WINO_NARROW=1: Winograd also for convolutions with cout <= dim below level 0 (add_resnet)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
                             // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
@@ -910,6 +911,11 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   double* stf = next_stats(e);
   const int c0 = h->C[0];
   CK(conv3x3(e, h->final_conv3, fin, fin_ld, 0, b.S1[0], c0, stf, fin_split));
+  if (h->fuse_final) {      // GroupNorm + Mish + mask inside the 1x1 projection: the normalised tensor is never stored
+    CK(launch_final_conv(b.S1[0], c0, h->final_w1->buf.p, h->final_b1->buf.p, e.mask, T, e.Bm, out, e.Bp, F, T, c0, e.s, stf,
+                         h->final_g->buf.p, h->final_b->buf.p));
+    return hipSuccess;
+  }
   CK(gn_apply(e, b.S1[0], 0, c0, stf, h->final_g, h->final_b, nullptr, nullptr, 0, false, false, b.S1[0], c0));
   CK(launch_final_conv(b.S1[0], c0, h->final_w1->buf.p, h->final_b1->buf.p, e.mask, T, e.Bm, out, e.Bp, F, T, c0, e.s));
   return hipSuccess;
@@ -1081,6 +1087,7 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   if (const char* wf = getenv("US_XCD_Z")) h->xcd_z = atoi(wf) != 0;
   if (const char* wf = getenv("US_PRESPLIT")) h->presplit = atoi(wf) != 0;
   if (const char* wf = getenv("US_ATTN_FUSE")) h->attn_fuse = atoi(wf) != 0;
+  if (const char* ff = getenv("US_FUSE_FINAL")) h->fuse_final = atoi(ff) != 0;
   if (flags & US_CREATE_EXACT_FP32) h->f16x3 = false;
   h->exact = !h->f16x3;
   h->build();

@@ -209,7 +209,8 @@ struct GnApplyArgs {
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
 // final_conv (1x1, C->1) of masked input, times mask: out[b][p] = (b0 + sum_c w[c]*h[p][c]*m)*m        (:199-201)
 hipError_t launch_final_conv(const float* h, int ld, const float* w, const float* b0, const float* mask, int mask_ld,
-                             int mask_bmod, float* out, int B, int H, int W, int C, hipStream_t s);
+                             int mask_bmod, float* out, int B, int H, int W, int C, hipStream_t s, const double* stats = nullptr,
+                             const float* gamma = nullptr, const float* beta = nullptr);   // stats: GroupNorm + Mish + mask of `h` on the fly
 
 // ---- linear attention --------------------------------------------------------------------------------
 // qkv: [B][n][384] (q | k | v, each heads*32).  Stage 1: per 128-row chunk, column max / sum-exp of k and the

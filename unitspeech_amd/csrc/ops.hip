@@ -298,11 +298,16 @@ hipError_t launch_gn_apply(const GnApplyArgs& a_in, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------
 // final_conv: 1x1, C -> 1 on the masked block output, times mask            (unitspeech.py:199-201)
-// half a wave (32 lanes x float4 = 128 channels per pass) per pixel
+// half a wave (32 lanes x float4 = 128 channels per pass) per pixel.  GN = true: `h` is the raw output of the final Block's
+// convolution and GroupNorm + Mish + mask (unitspeech.py:198, Block :27-33) are applied on the fly with gn_apply_kernel's arithmetic,
+// so the normalised tensor is never stored (126 MB less written and read per item at 80 x 1024).
 // ---------------------------------------------------------------------------------------------------
+template <bool GN>
 __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict__ h, int ld, const float* __restrict__ w,
                                                          const float* __restrict__ b0, const float* __restrict__ mask, int mask_ld,
-                                                         int mask_bmod, float* __restrict__ out, int W, long long n, int C) {
+                                                         int mask_bmod, float* __restrict__ out, int W, long long n, int C,
+                                                         const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta) {
   const int b = blockIdx.y;
   const int l32 = threadIdx.x & 31;
   const long long half0 = (blockIdx.x * 256LL + threadIdx.x) >> 5;
@@ -310,29 +315,67 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
   const float* hb = h + (long long)b * n * ld;
   const float* mb = mask + (long long)(b % mask_bmod) * mask_ld;
   const float bias = b0[0];
+  __shared__ float s_mean[kGroups], s_rstd[kGroups];
+  const int cg = C / kGroups;
+  if constexpr (GN) {
+    if (threadIdx.x < kGroups) {
+      const double cnt = (double)n * cg;
+      double mean = stat_read(stats, b, threadIdx.x, 0) / cnt;
+      double var = stat_read(stats, b, threadIdx.x, 1) / cnt - mean * mean;
+      if (var < 0) var = 0;
+      s_mean[threadIdx.x] = (float)mean;
+      s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+  }
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+  auto fold = [&](int c) {
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int gk = (c + k) / cg;
+      sc[k] = s_rstd[gk] * ga[k];
+      sh[k] = be[k] - s_mean[gk] * sc[k];
+    }
+  };
+  const bool one_pass = C <= 128;
+  if constexpr (GN) {
+    if (one_pass && l32 * 4 < C) fold(l32 * 4);
+  }
   for (long long p = half0; p < n; p += nhalf) {
     float acc = 0.f;
+    const float m = mb[(int)(p % W)];
     for (int c = l32 * 4; c < C; c += 128) {
       f32x4 v = *reinterpret_cast<const f32x4*>(hb + p * ld + c);
       f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+      if constexpr (GN) {
+        if (!one_pass) fold(c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = mish_f(v[k] * sc[k] + sh[k]) * m;
+      }
       acc += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3];
     }
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (l32 == 0) {
-      float m = mb[(int)(p % W)];
-      out[(long long)b * n + p] = (acc * m + bias) * m;
-    }
+    if (l32 == 0) out[(long long)b * n + p] = (acc * m + bias) * m;
   }
 }
 
 hipError_t launch_final_conv(const float* h, int ld, const float* w, const float* b0, const float* mask, int mask_ld,
-                             int mask_bmod, float* out, int B, int H, int W, int C, hipStream_t s) {
+                             int mask_bmod, float* out, int B, int H, int W, int C, hipStream_t s, const double* stats,
+                             const float* gamma, const float* beta) {
   if (C % 4 != 0) return hipErrorInvalidValue;
+  if (stats && (C % kGroups != 0 || !gamma || !beta)) return hipErrorInvalidValue;
   long long n = (long long)H * W;
   int blocks = (int)((n + 7) / 8);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(final_conv_kernel, dim3(blocks, B), dim3(256), 0, s, h, ld, w, b0, mask, mask_ld, mask_bmod, out, W, n, C);
+  if (stats)
+    hipLaunchKernelGGL(final_conv_kernel<true>, dim3(blocks, B), dim3(256), 0, s, h, ld, w, b0, mask, mask_ld, mask_bmod, out, W, n, C,
+                       stats, gamma, beta);
+  else
+    hipLaunchKernelGGL(final_conv_kernel<false>, dim3(blocks, B), dim3(256), 0, s, h, ld, w, b0, mask, mask_ld, mask_bmod, out, W, n, C,
+                       nullptr, nullptr, nullptr);
   return hipGetLastError();
 }
 
