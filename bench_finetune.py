@@ -82,6 +82,13 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
+    last_loss = loss.item()
+    # time to ENQUEUE an iteration, taken on an empty queue (two untimed extra iterations): the host is the limit when it is close to dt
+    t1 = time.perf_counter()
+    for _ in range(2):
+        step()
+    host_dt = (time.perf_counter() - t1) / 2
+    torch.cuda.synchronize()
     eng = model._get_engine()
     fwd_flops = eng.lib.us_estimator_flops(eng.handle, a.segment)          # direct-convolution count of SURVEY.md 8(d), one item
     step_flops = 3.0 * fwd_flops                                           # forward + data gradients + weight gradients
@@ -90,7 +97,7 @@ def main():
            "higher_is_better": False, "n_gpus": 1, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"finetune.py:131-165 inner loop, B=1, {a.segment}-frame crops of a {L}-frame utterance, full-size decoder, "
                                   f"Adam lr 2e-5, clip 1.0", "optimizer": a.optimizer, "launch": "eager" if graph is None else "hip graph"},
-           "iters": a.iters, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": loss.item(),
+           "iters": a.iters, "host_enqueue_s_per_iter": host_dt, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": last_loss,
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                         "flops_per_iteration": step_flops,
                         "flops_basis": "direct-form convolution FLOPs (3x the forward count of SURVEY.md 8(d)) over wall time of the whole "

@@ -306,3 +306,22 @@ def test_pretraining_batch_loss_and_every_gradient_vs_oracle_autograd(sd_np):
     assert abs(l_x - float(loss_ref)) <= 2e-6 * max(1.0, abs(float(loss_ref)))
     assert w_new <= 1e-6 and w_x <= 1e-6
     assert med_new <= 3e-6 and med_x <= 3e-6
+
+
+def test_weight_gradient_chains_on_the_second_stream_give_the_gradients_of_the_one_stream_backward(sd_np, monkeypatch):
+    """The eager backward runs each parameter's max -> zero -> wgrad -> unpack chain on the handle's second stream, ordered against the
+    data-gradient chain by events in both directions (train_host.inc, BwdCtx).  US_WGRAD_STREAM=0 (read when the handle is created) keeps
+    everything on the caller's stream: same gradients up to the order of the fp32 atomics (four ragged crops; every per-level buffer
+    of the backward pass is written at least twice)."""
+    args = _crops(4, 176, key=57)
+    l2, two = _hip_grads(sd_np, *args)
+    monkeypatch.setenv("US_WGRAD_STREAM", "0")
+    l1_, one = _hip_grads(sd_np, *args)
+    assert l1_ == l2 and len(two) == 228
+    whole, median, worst = _rel(two, one)
+    print(f"\ntwo streams vs one: whole-gradient relative L2 {whole:.2e}, median tensor {median:.2e}, worst {worst:.2e}")
+    assert whole <= 2e-7 and worst <= 1e-4
+    monkeypatch.delenv("US_WGRAD_STREAM")
+    _, again = _hip_grads(sd_np, *args)     # a second two-stream handle: same result again
+    w2, _, worst2 = _rel(again, one)
+    assert w2 <= 2e-7 and worst2 <= 1e-4
