@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=2, help="iterations of the CPU oracle (torch autograd + Adam) timed")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured HIP graph (unitspeech_amd.graph)")
+    ap.add_argument("--backward", choices=["graph", "eager"], default=None,
+                    help="with the graph: the backward captured too, or run eagerly after the replayed forward (FineTuneGraph; default: its own)")
     ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
                     help="fused: HIP clip+Adam in 3 launches (unitspeech_amd.FusedAdam); torch: clip_grad_norm_ + torch.optim.Adam")
     a = ap.parse_args()
@@ -57,7 +59,7 @@ def main():
     graph = None
     if not a.no_graph:
         from unitspeech_amd.graph import FineTuneGraph
-        graph = FineTuneGraph(model, spk_d, 1, a.segment, cfg.n_feats)
+        graph = FineTuneGraph(model, spk_d, 1, a.segment, cfg.n_feats, backward=a.backward)
 
     def step():
         if graph is not None:
@@ -96,7 +98,7 @@ def main():
     res = {"metric": "fine-tune seconds/iteration (B=1, 176-frame crop, fwd+bwd+clip+Adam)", "value": dt, "unit": "s/iter",
            "higher_is_better": False, "n_gpus": 1, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"finetune.py:131-165 inner loop, B=1, {a.segment}-frame crops of a {L}-frame utterance, full-size decoder, "
-                                  f"Adam lr 2e-5, clip 1.0", "optimizer": a.optimizer, "launch": "eager" if graph is None else "hip graph"},
+                                  f"Adam lr 2e-5, clip 1.0", "optimizer": a.optimizer, "launch": "eager" if graph is None else ("hip graph" if graph.backward == "graph" else "hip graph (forward) + eager backward")},
            "iters": a.iters, "host_enqueue_s_per_iter": host_dt, "est_500_iter_s": 500 * dt, "first_losses": losses, "last_loss": last_loss,
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                         "flops_per_iteration": step_flops,

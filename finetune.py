@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--n_iters", type=int, default=500, help="Number of fine-tuning iterations.")
     ap.add_argument("--learning_rate", type=float, default=2e-5, help="Learning rate of the optimizer during fine-tuning.")
     ap.add_argument("--torch_optimizer", action="store_true", help="clip_grad_norm_ + torch.optim.Adam instead of the HIP clip+Adam")
-    ap.add_argument("--no_graph", action="store_true", help="launch every kernel of an iteration eagerly instead of replaying one captured HIP graph")
+    ap.add_argument("--no_graph", action="store_true", help="launch every kernel of an iteration eagerly instead of replaying the captured HIP graph of the forward (unitspeech_amd.graph)")
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--learned_frontend", action="store_true", help="--synthetic: cond_x from the HIP unit encoder (seeded weights) on synthetic units")
     ap.add_argument("--reference_root", type=str, default=None)

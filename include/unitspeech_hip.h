@@ -135,17 +135,23 @@ double us_estimator_flops(us_handle h, int T);
  * US_EINVAL when tape_id is not live (consumed, released or evicted) -- a backward never runs on another forward's tape.
  * grad_x, grad_mu [B, n_feats, T], grad_spk [B, spk_emb_dim]: optional (NULL = not wanted) gradients w.r.t. the inputs
  * x, mu and spk_emb (the reference's trainers reach the text / unit encoder through them: train_STEP1.py:381,
- * train_STEP2.py:299).  The tape is consumed by the call. */
+ * train_STEP2.py:299).  The tape is consumed by the call (unless US_BACKWARD_KEEP_TAPE, below).  Outside a stream capture the call
+ * runs the weight-gradient launches on a second stream of the handle, fenced against `stream` by events on both sides: when it
+ * returns, everything it enqueued is ordered before whatever the caller enqueues on `stream` next (US_WGRAD_STREAM=0: one stream). */
 size_t us_train_workspace_bytes(us_handle h, int B, int T);
 int us_estimator_forward_train(us_handle h, const float* x, const float* mask, const float* mu, const float* t,
                                const float* spk, float* out, int B, int T, void* workspace, size_t workspace_bytes,
                                uint64_t* tape_id, us_stream stream);
-/* flags: bit 0 = the gradient buffers are already zero (e.g. views of one zero-filled blob): skips 228 fill launches.
+/* flags: US_BACKWARD_GRADS_ZEROED (bit 0) = the gradient buffers are already zero (e.g. views of one zero-filled blob): skips 228
+ * fill launches.  US_BACKWARD_KEEP_TAPE (bit 1) = the tape stays live after a successful call: for a caller that re-runs the SAME forward
+ * launches into the SAME workspace itself (a captured HIP graph of the forward, replayed per iteration) and then calls the backward
+ * again -- the record names buffers, not values.  Release it with us_tape_release.
  * Range of grad_out: any.  The backward GEMMs split their fp32 operands into two fp16 planes, which carry full
  * precision from about 6e-5 upwards, while the gradient of a mean-reduced loss over B*F*T elements is ~1/(B*F*T) and a caller's loss
  * weight or accumulation factor comes on top: the entry point itself multiplies grad_out by the power of two that brings its largest
  * magnitude to [2^-7, 2^-6) (chosen on the device from the data), runs the pass, and multiplies everything it returns by the inverse
  * -- exact, because the pass is linear in grad_out.  grad_out is not modified. */
+enum { US_BACKWARD_GRADS_ZEROED = 1, US_BACKWARD_KEEP_TAPE = 2 };
 int us_estimator_backward(us_handle h, uint64_t tape_id, const float* grad_out, int B, int T, const char* const* keys,
                           float* const* grads, int n_grads, int flags, float* grad_x, float* grad_mu, float* grad_spk,
                           us_stream stream);

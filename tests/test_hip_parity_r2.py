@@ -353,7 +353,10 @@ def test_invalidate_weights_after_in_place_data_write():
 # ---------------------------------------------------------------------------------------------------------------
 # the fine-tune iteration as one HIP graph: same loss trajectory and parameters as the eager launches
 # ---------------------------------------------------------------------------------------------------------------
-def test_finetune_graph_replay_matches_eager_iterations():
+@pytest.mark.parametrize("backward", ["graph", "eager"])
+def test_finetune_graph_replay_matches_eager_iterations(backward):
+    """backward="graph": forward + backward of an iteration replayed as one HIP graph; "eager" (FineTuneGraph's default): the forward
+    replayed, `loss.backward(retain_graph=True)` launched per iteration on the tape the library keeps live (US_BACKWARD_KEEP_TAPE)."""
     import random
     from unitspeech_amd import FusedAdam
     from unitspeech_amd.graph import FineTuneGraph
@@ -371,7 +374,7 @@ def test_finetune_graph_replay_matches_eager_iterations():
         model = make_model(TINY).train()
         opt = FusedAdam(model.parameters(), lr=1e-3)         # large enough that a missed weight re-pack would show in the next loss
         random.seed(7); torch.manual_seed(7)
-        graph = FineTuneGraph(model, spk, 1, seg, 80) if use_graph else None
+        graph = FineTuneGraph(model, spk, 1, seg, 80, backward=backward) if use_graph else None
         losses = []
         for _ in range(iters):
             if graph is not None:

@@ -13,6 +13,7 @@ from . import _build
 US_OK = 0
 US_CREATE_EXACT_FP32 = 1
 US_RANGE_ACT, US_RANGE_WEIGHT = 1, 2
+US_BACKWARD_GRADS_ZEROED, US_BACKWARD_KEEP_TAPE = 1, 2
 ERRORS = {-1: "EINVAL", -2: "ENOKEY", -3: "ESHAPE", -4: "EWEIGHTS", -5: "EWORKSPACE", -6: "EHIP"}
 
 

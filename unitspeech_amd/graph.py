@@ -1,4 +1,4 @@
-"""The fine-tune iteration as ONE HIP graph.
+"""The fine-tune iteration as a HIP graph (forward, or forward + backward).
 
 A speaker-adaptation iteration (finetune.py:131-165) is ~900 kernel launches of a few microseconds each on a 176-frame crop: the
 GPU work is a few milliseconds, the launch stream 13-14.  Shapes, parameter storage and workspaces never change across the 500
@@ -14,15 +14,29 @@ host: the random crop (Python's `random`, as in the reference) and the optimiser
 
 The gaussian draws inside (`torch.rand` for t, `torch.randn` for z) use torch's graph-safe Philox bookkeeping, so the stream of
 random numbers, hence the loss trajectory, is the eager one.
+
+`backward="eager"` (the default; `UNITSPEECH_FT_BACKWARD=graph` or `backward="graph"` captures everything as described above): only the forward (re-pack, score network with its tape, objective) is captured; `loss.backward(retain_graph=True)`
+then runs per iteration as ordinary launches on the retained autograd graph, whose saved tensors are the capture's static buffers
+(the library keeps the tape live: US_BACKWARD_KEEP_TAPE).  Outside a capture the library's backward runs its weight-gradient chains
+on a second stream, which a replayed graph cannot do at a profit, and the host enqueues the backward while the GPU is
+still replaying the forward.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 
 
 class FineTuneGraph:
-    def __init__(self, decoder, spk_emb: torch.Tensor, batch: int, segment_size: int, n_feats: int = None, warmup: int = 2):
+    def __init__(self, decoder, spk_emb: torch.Tensor, batch: int, segment_size: int, n_feats: int = None, warmup: int = 2,
+                 backward: str = None):
         dev = next(decoder.parameters()).device
+        if backward is None:
+            backward = os.environ.get("UNITSPEECH_FT_BACKWARD", "eager")      # measured: 10.5 vs 11.1 ms per iteration (DESIGN.md 7)
+        if backward not in ("graph", "eager"):
+            raise ValueError(f"FineTuneGraph: backward must be 'graph' or 'eager', got {backward!r}")
+        self.backward = backward
         if dev.type != "cuda":
             raise RuntimeError("FineTuneGraph needs the decoder on a ROCm device")
         self.decoder = decoder
@@ -54,12 +68,24 @@ class FineTuneGraph:
         self.graph = torch.cuda.CUDAGraph()
         # capture on the warm-up stream: the AccumulateGrad nodes created there stay bound to it, and a capture on another stream would
         # only work through autograd's cross-stream waits happening to be captured too
-        with torch.cuda.graph(self.graph, stream=side):
-            loss, _ = decoder.compute_loss(self.y, self.mask, self.cond, spk_emb=self.spk)
-            loss.backward()
+        self._engine = decoder._get_engine()
+        self._side = side
+        self._dev = dev
+        if backward == "graph":
+            with torch.cuda.graph(self.graph, stream=side):
+                loss, _ = decoder.compute_loss(self.y, self.mask, self.cond, spk_emb=self.spk)
+                loss.backward()
+            self._loss_live = None
+        else:
+            self._engine.keep_tapes = True            # the forward's record must survive its backward calls (_EstimatorFn)
+            try:
+                with torch.cuda.graph(self.graph, stream=side):
+                    loss, _ = decoder.compute_loss(self.y, self.mask, self.cond, spk_emb=self.spk)
+            finally:
+                self._engine.keep_tapes = False
+            self._loss_live = loss                    # holds the autograd graph; its saved tensors are the capture's static buffers
         self.loss = loss.detach()
         # the graph holds raw pointers: parameter and gradient storage, the engine's packed weights and staging tables
-        self._engine = decoder._get_engine()
         self._handle = self._engine.handle.value
         self._ptrs = [(p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0) for p in self.params]
 
@@ -69,13 +95,31 @@ class FineTuneGraph:
             raise RuntimeError("FineTuneGraph: the decoder's engine was re-created (device move, `exact` switched) after capture; "
                                "build a new FineTuneGraph")
         for p, (dp, gp) in zip(self.params, self._ptrs):
-            if p.data_ptr() != dp or (p.grad is not None and p.grad.data_ptr() != gp) or (p.grad is None and gp != 0):
+            if p.data_ptr() != dp:
+                raise RuntimeError("FineTuneGraph: parameter storage changed after capture (decoder.to(), load_state_dict(assign=True), "
+                                   "...); build a new FineTuneGraph")
+            if self.backward == "eager":
+                continue                              # gradients are fresh tensors every iteration
+            if (p.grad is not None and p.grad.data_ptr() != gp) or (p.grad is None and gp != 0):
                 raise RuntimeError("FineTuneGraph: parameter or gradient storage changed after capture (decoder.to(), "
                                    "load_state_dict(assign=True), zero_grad(set_to_none=True), ...); build a new FineTuneGraph")
 
     def step(self, cond_x, y, y_lengths, attn) -> torch.Tensor:
-        """One `fine_tune` call plus `loss.backward()`: gradients land in `p.grad` (static tensors), returns the loss (static)."""
+        """One `fine_tune` call plus `loss.backward()`: gradients land in `p.grad` (static tensors with backward="graph", fresh views of one
+        blob per iteration otherwise), returns the loss (a static tensor)."""
         self._check_alive()
         self.decoder.fine_tune_segment(cond_x, y, y_lengths, attn, self.segment_size, self.n_feats, out=(self.y, self.mask, self.cond))
-        self.graph.replay()
+        if self.backward == "graph":
+            self.graph.replay()
+            return self.loss
+        # forward graph and eager backward on the capture stream (the autograd nodes are bound to it), fenced against the caller's stream on
+        # both sides: the crop above and the optimiser step after this call run there
+        cur = torch.cuda.current_stream(self._dev)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self.graph.replay()
+            for p in self.params:
+                p.grad = None
+            self._loss_live.backward(retain_graph=True)
+        cur.wait_stream(self._side)
         return self.loss

@@ -293,6 +293,7 @@ class _EstimatorFn(torch.autograd.Function):
         _lib.check(rc, eng.handle, "us_estimator_forward_train")
         ctx.eng, ctx.ws, ctx.keys, ctx.dev = eng, ws, keys, dev
         ctx.tape = _TapeRef(eng, tape.value)
+        ctx.keep = bool(getattr(eng, "keep_tapes", False))      # graph.FineTuneGraph: forward replayed as a graph, backward called per iteration
         ctx.shape = (B, F, T)
         ctx.spk_shape = tuple(spk.shape)
         ctx.inputs = (x, mask, mu, t, spk)      # keep the operands alive until backward has been enqueued
@@ -323,14 +324,17 @@ class _EstimatorFn(torch.autograd.Function):
         gspk = torch.empty(ctx.spk_shape, dtype=torch.float32, device=dev) if need_spk else None
         opt = lambda v: _dev_ptr(v) if v is not None else None
         with torch.cuda.device(dev):
-            rc = eng.lib.us_estimator_backward(eng.handle, C.c_uint64(ctx.tape.tape_id), _dev_ptr(g), B, T, ckeys, cptrs, n, 1,
+            flags = _lib.US_BACKWARD_GRADS_ZEROED | (_lib.US_BACKWARD_KEEP_TAPE if ctx.keep else 0)
+            rc = eng.lib.us_estimator_backward(eng.handle, C.c_uint64(ctx.tape.tape_id), _dev_ptr(g), B, T, ckeys, cptrs, n, flags,
                                                opt(gx), opt(gmu), opt(gspk), _stream())
-        ctx.tape.live = False                   # consumed (or refused) by the library either way
+        if not ctx.keep or rc != 0:
+            ctx.tape.live = False               # consumed (or refused) by the library either way
         _lib.check(rc, eng.handle, "us_estimator_backward")
         if not torch.cuda.is_current_stream_capturing():
             eng.range_post()
-        ctx.ws = None
-        ctx.inputs = None
+        if not ctx.keep:
+            ctx.ws = None
+            ctx.inputs = None
         eng.last_grad_blob = blob               # data-parallel training all-reduces this one buffer (sharding.allreduce_gradients)
         return (None, None, gx, None, gmu, None, gspk, None, *[gr.to(dt) for gr, (_, dt) in zip(grads, ctx.param_meta)])
 
