@@ -108,7 +108,7 @@ if sched and n % len(sched) == 0 and n:
     res["conv_hbm_side_bytes_per_evaluation"] = tot_bytes
 # every kernel of the score network, per evaluation: the trace holds as many evaluations as final_conv_kernel dispatches; weight packs,
 # table copies and torch's own kernels (set-up, once per handle) are left out
-n_eval = max(calls.get("final_conv_kernel", 0), 1)
+n_eval = max(sum(v for k, v in calls.items() if k.startswith("final_conv_kernel")), 1)      # (a template since round 3: final_conv_kernel<true>)
 setup = ("pack_", "copy_table", "copy_rows", "fill_", "at::", "__amd_rocclr", "l2_normalize", "mul_mask", "finish_mel", "Cijk")
 all_bytes = 0.0
 for k, o in res["kernels"].items():
