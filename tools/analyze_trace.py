@@ -16,6 +16,7 @@ ap.add_argument("--bp", type=int, default=3)
 ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--wino-min-level", type=int, default=1, help="levels >= this run their 3x3 convs as Winograd (US_WINO_MIN_LEVEL)")
 ap.add_argument("--wino-narrow", action="store_true", help="US_WINO_NARROW=1: Winograd also where cout <= dim (the last up level)")
+ap.add_argument("--no-split-copy", action="store_true", help="US_SPLIT_COPY=0: res_conv stays the last launch of every ResnetBlock")
 a = ap.parse_args()
 
 F, T, BP = 80, a.frames, a.bp
@@ -38,10 +39,16 @@ def conv(name, l_out_pixels, cin, cout, taps, wino=False):
 
 
 def resnet(name, l, cin, cout, first=False):
+    wino = l >= WMIN and (cout > a.dim or a.wino_narrow)
+    # a block whose successor takes a split copy of its output (direct convolutions: the narrow last up level) runs res_conv FIRST and
+    # lets block2's GroupNorm pass add it (decoder.hip, resnet(): split_out)
+    res_first = cin != cout and not first and not wino and not a.no_split_copy
+    if res_first:
+        conv(f"{name}.res 1x1 {cin}->{cout} L{l}", npx(l), cin, cout, 1)
     if not first:
-        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=l >= WMIN and (cout > a.dim or a.wino_narrow))
-    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=l >= WMIN and (cout > a.dim or a.wino_narrow))
-    if cin != cout and not first:
+        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=wino)
+    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=wino)
+    if cin != cout and not first and not res_first:
         conv(f"{name}.res 1x1 {cin}->{cout} L{l}", npx(l), cin, cout, 1)
 
 

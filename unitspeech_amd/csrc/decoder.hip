@@ -648,7 +648,7 @@ hipError_t conv_up(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
 
 hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* stats, const Slot* g, const Slot* bta,
                     const float* temb, const float* res, int res_ld, bool res_masked, bool post_mask, float* out, int out_ld,
-                    bool out_split = false) {
+                    bool out_split = false, float* split_copy = nullptr) {
   GnApplyArgs a;
   memset(&a, 0, sizeof a);
   a.y = y; a.y_ld = C;
@@ -660,6 +660,7 @@ hipError_t gn_apply(EvalCtx& e, const float* y, int level, int C, const double* 
   a.post_mask = post_mask ? 1 : 0;
   a.out_split = out_split ? 1 : 0;
   a.out = out; a.out_ld = out_ld;
+  a.out2 = split_copy; a.out2_ld = C;
   a.B = e.Bp; a.H = e.h->cfg.n_feats >> level; a.W = e.T >> level; a.C = C;
   return launch_gn_apply(a, e.s);
 }
@@ -681,7 +682,11 @@ inline bool direct_presplit(EvalCtx& e, const ConvW& w, int C, int tmp_ld) {
 // through `x * mask` (next ResnetBlock / concat), so the mask is applied to what is stored; false when the consumer
 // is the attention, which reads the raw tensor (padded frames included, :91).
 // in_split: `in` is in the two-plane fp16 form (only legal when block1's convolution and res_conv are direct f16x3 convolutions: resnet_takes_split())
-hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, float* out, int out_ld, bool mask_out, bool in_split = false) {
+// split_out: the block also stores its result in the two-plane form there (ld = cout), for the next block's `in_copy`;
+// in_copy: the input once more in the two-plane form (ld = cin): block1's direct f16x3 convolution reads it without the in-kernel split
+// while the identity residual keeps reading the fp32 `in` (next_takes_split_copy()).
+hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, float* out, int out_ld, bool mask_out, bool in_split = false,
+                  float* split_out = nullptr, const float* in_copy = nullptr) {
   Buffers& b = *e.b;
   const int l = r.level;
   float* S1 = b.S1[l];
@@ -690,7 +695,18 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
   double* st1 = next_stats(e);
   double* st2 = next_stats(e);
   if (in_split && !r.has_res) return hipErrorInvalidValue;      // the identity residual would need the fp32 tensor
-  CK(conv3x3(e, r.c1, in, in_ld, l, S1, r.cout, st1, in_split));
+  if (in_copy && (in_split || r.has_res)) return hipErrorInvalidValue;
+  if (split_out && (out_ld != r.cout || split_out == out)) return hipErrorInvalidValue;
+  // with a split copy to write, res_conv runs first into a spare buffer and block2's GroupNorm pass -- the last writer then -- adds it
+  // (the same two fp32 operands, (conv + bias) + h, as when the convolution's epilogue adds h) and stores both forms
+  float* R = nullptr;
+  if (split_out && r.has_res) {
+    if (r.cout > 3 * kHidden) return hipErrorInvalidValue;
+    R = b.QKV[l];                                                // the level's attention scratch: free while a ResnetBlock runs
+    CK(conv1x1(e, r.res, in, in_ld, l, false, R, r.cout, nullptr, 0, nullptr, nullptr, 0, nullptr, in_split));
+  }
+  if (in_copy) CK(conv3x3(e, r.c1, in_copy, r.c1.cin, l, S1, r.cout, st1, true));
+  else CK(conv3x3(e, r.c1, in, in_ld, l, S1, r.cout, st1, in_split));
   if (r.c2.w->wino.p && b.wino_v && e.h->wino_fuse_gn && gn_wino_input_supported(r.cout)) {
     // block1's GroupNorm + Mish + time embedding (pre-masked for block2's `x * mask`, :54) evaluated inside the Winograd input
     // transform of block2's conv: h1 is never written
@@ -708,13 +724,23 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
       CK(conv3x3(e, r.c2, S1, r.cout, l, S2, r.cout, st2));
     }
   }
-  if (r.has_res) {
+  if (R) {
+    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, R, r.cout, false, mask_out, out, out_ld, false, split_out));
+  } else if (r.has_res) {
     CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, nullptr, 0, false, false, out, out_ld));
     CK(conv1x1(e, r.res, in, in_ld, l, mask_out, out, out_ld, out, out_ld, nullptr, nullptr, 0, nullptr, in_split));
   } else {
-    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, in, in_ld, false, mask_out, out, out_ld));
+    CK(gn_apply(e, S2, l, r.cout, st2, r.g2, r.b2, nullptr, in, in_ld, false, mask_out, out, out_ld, false, split_out));
   }
   return hipSuccess;
+}
+
+// r2 of a level takes its input (r1's output) a second time in the two-plane form when its block1 convolution is a direct f16x3 one and
+// it has no res_conv (the identity residual reads the fp32 copy); the copy lives in r2's own output buffer, which is free until its end
+inline bool next_takes_split_copy(EvalCtx& e, const ResnetW& r2) {
+  static const bool on = [] { const char* p = getenv("US_SPLIT_COPY"); return !p || atoi(p) != 0; }();
+  return on && e.h->presplit && e.h->f16x3 && e.h->f16x3_direct && !r2.has_res && !r2.first && direct_presplit(e, r2.c1, r2.c1.cin, r2.c1.cin) &&
+         r2.c1.cin == r2.cout;
 }
 
 // a ResnetBlock whose two readers of its input (block1's 3x3, res_conv) are both direct f16x3 convolutions can take that input pre-split
@@ -845,6 +871,7 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   for (int l = 0; l < L; ++l) {
     auto& d = h->downs[l];
     const int c = h->C[l];
+    const bool r2_copy = next_takes_split_copy(e, d.r2);
     if (l == 0) {
       // first ResnetBlock: 2-channel convs on the direct kernel
       const ResnetW& r = d.r1;
@@ -874,13 +901,14 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
         ga.res2_in = b.in2; ga.res2_w = r.res.w->buf.p; ga.res2_b = r.res.b->buf.p;
         ga.post_mask = 1;
         ga.out = b.P[0]; ga.out_ld = c;
+        if (r2_copy) { ga.out2 = b.Q[0]; ga.out2_ld = c; }
         ga.B = e.Bp; ga.H = F; ga.W = T; ga.C = c;
         CK(launch_gn_apply(ga, e.s));
       }
     } else {
-      CK(resnet(e, d.r1, cur, cur_ld, b.P[l], c, true));
+      CK(resnet(e, d.r1, cur, cur_ld, b.P[l], c, true, false, r2_copy ? b.Q[l] : nullptr));
     }
-    CK(resnet(e, d.r2, b.P[l], c, b.Q[l], c, false));
+    CK(resnet(e, d.r2, b.P[l], c, b.Q[l], c, false, false, nullptr, r2_copy ? b.Q[l] : nullptr));
     float* hid = l == 0 ? b.P[0] : b.CAT[l] + c;
     int hid_ld = l == 0 ? c : 2 * c;
     CK(attention(e, d.a, b.Q[l], c, hid, hid_ld, hid_split[l]));
@@ -903,8 +931,9 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
   for (int u = 0; u < L - 1; ++u) {
     auto& up = h->ups[u];
     const int l = up.r1.level, co = up.r1.cout;
-    CK(resnet(e, up.r1, b.CAT[l], 2 * h->C[l], b.P[l], co, true, l <= L - 2 && hid_split[l]));
-    CK(resnet(e, up.r2, b.P[l], co, b.Q[l], co, false));
+    const bool r2_copy = next_takes_split_copy(e, up.r2);
+    CK(resnet(e, up.r1, b.CAT[l], 2 * h->C[l], b.P[l], co, true, l <= L - 2 && hid_split[l], r2_copy ? b.Q[l] : nullptr));
+    CK(resnet(e, up.r2, b.P[l], co, b.Q[l], co, false, false, nullptr, r2_copy ? b.Q[l] : nullptr));
     CK(attention(e, up.a, b.Q[l], co, b.P[l], co, up_split[l]));
     float* dst = (l - 1 >= 1) ? b.CAT[l - 1] : b.U0;
     int dst_ld = (l - 1 >= 1) ? 2 * h->C[l - 1] : h->C[0];

@@ -204,6 +204,8 @@ struct GnApplyArgs {
                                                            // as fp32) that a direct f16x3 convolution takes as a pre-split A operand;
                                                            // out must not alias y (a quad's lo plane lands on its neighbour's input)
   float* out; int out_ld;
+  float* out2; int out2_ld;                                // optional second copy of the result in the two-plane form (out stays fp32): a tensor
+                                                           // read both as a residual (fp32) and by a direct f16x3 convolution (pre-split)
   int B, H, W, C;
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);

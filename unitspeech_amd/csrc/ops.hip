@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
   __syncthreads();
   const float* yb = a.y + (long long)b * n * a.y_ld;
   float* ob = a.out + (long long)b * n * a.out_ld;
+  float* o2b = a.out2 ? a.out2 + (long long)b * n * a.out2_ld : nullptr;
   const float* rb = a.res ? a.res + (long long)b * n * a.res_ld : nullptr;
   const float* mb = a.mask + (long long)(b % a.mask_bmod) * a.mask_ld;
   const float* tb = a.temb ? a.temb + (long long)b * a.temb_ld : nullptr;
@@ -273,13 +274,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs a) {
     } else {
       *reinterpret_cast<f32x4*>(ob + p * a.out_ld + c) = o;
     }
+    if (o2b) {
+      typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+      half4_t hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        us_half h, l;
+        split_f16x3(o[k], h, l, over);
+        hi[k] = h;
+        lo[k] = l;
+      }
+      _Float16* oh = reinterpret_cast<_Float16*>(o2b + p * a.out2_ld) + 2 * (c & ~7) + (c & 7);
+      *reinterpret_cast<half4_t*>(oh) = hi;
+      *reinterpret_cast<half4_t*>(oh + 8) = lo;
+    }
     if (fixed_quad) {
       p += rpi;
       w += wstep;
       if (w >= a.W) w -= a.W;
     }
   }
-  if (a.out_split) range_report(a.range_flag, over, kRangeAct);
+  if (a.out_split || a.out2) range_report(a.range_flag, over, kRangeAct);
 }
 
 hipError_t launch_gn_apply(const GnApplyArgs& a_in, hipStream_t s) {
@@ -288,6 +303,7 @@ hipError_t launch_gn_apply(const GnApplyArgs& a_in, hipStream_t s) {
   if (a.C % 4 != 0 || a.C % kGroups != 0 || a.y_ld % 4 != 0 || a.out_ld % 4 != 0 || (a.res && a.res_ld % 4 != 0))
     return hipErrorInvalidValue;
   if (a.out_split && (a.C % 8 != 0 || a.out_ld % 8 != 0 || a.out == a.y)) return hipErrorInvalidValue;
+  if (a.out2 && (a.C % 8 != 0 || a.out2_ld % 8 != 0 || a.out2 == a.y || a.out2 == a.out || a.out2 == a.res)) return hipErrorInvalidValue;
   long long total = (long long)a.H * a.W * (a.C / 4);
   int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
   if (blocks < 1) blocks = 1;
