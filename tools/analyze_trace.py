@@ -16,6 +16,7 @@ ap.add_argument("--bp", type=int, default=3)
 ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--wino-min-level", type=int, default=1, help="levels >= this run their 3x3 convs as Winograd (US_WINO_MIN_LEVEL)")
 ap.add_argument("--wino-narrow", action="store_true", help="US_WINO_NARROW=1: Winograd also where cout <= dim (the last up level)")
+ap.add_argument("--no-wtotal", action="store_true", help="US_ATTN_WTOTAL=0: q is computed and stored at every level")
 ap.add_argument("--no-split-copy", action="store_true", help="US_SPLIT_COPY=0: res_conv stays the last launch of every ResnetBlock")
 a = ap.parse_args()
 
@@ -53,6 +54,11 @@ def resnet(name, l, cin, cout, first=False):
 
 
 def attn(name, l, c):
+    if l == 0 and c <= 128 and not a.no_wtotal:
+        # q folded away (decoder.hip, attention(): W_total): to_qkv computes k | v only, the output projection is C x C on x itself
+        conv(f"{name}.kv 1x1 {c}->256 L{l}", npx(l), c, 256, 1)
+        conv(f"{name}.out 1x1 {c}->{c} L{l} (W_total)", npx(l), c, c, 1)
+        return
     conv(f"{name}.qkv 1x1 {c}->384 L{l}", npx(l), c, 384, 1)
     conv(f"{name}.out 1x1 128->{c} L{l}", npx(l), 128, c, 1)
 

@@ -306,6 +306,68 @@ hipError_t launch_attn_merge(const float* part_ctx, const float* part_m, const f
   return hipGetLastError();
 }
 
+// W_total[b][n][k] = sum_j W_out[n][j] T[j][k],  T[h*32 + e][k] = sum_d ctx[b][h][d][e] W_q[h*32 + d][k]
+// (out = W_out (ctx^T q) with q = W_q x, unitspeech.py:95-100, re-associated: the [n][128] tensor q is never formed).
+// Block (k tile of 32, item): T's tile in LDS, then every thread owns pieces of 8 consecutive k of one output channel n: 32 bytes of the
+// conv kernel's packed weight ([C/32][C][4 groups x (8 hi | 8 lo)] in the two-plane form, [C/bk][C][bk] floats otherwise).
+__global__ __launch_bounds__(256) void attn_wtotal_kernel(const float* __restrict__ ctx, const float* __restrict__ wout,
+                                                          const float* __restrict__ wq, float* __restrict__ wtotal, int C, int bk, int f16,
+                                                          unsigned* range_flag) {
+  __shared__ float s_T[kHidden][33];
+  const int b = blockIdx.y, k0 = blockIdx.x * 32;
+  const float* cx = ctx + (long long)b * kHeads * kDimHead * kDimHead;
+  for (int i = threadIdx.x; i < kHidden * 32; i += 256) {
+    const int j = i >> 5, kk = i & 31;
+    const int h = j / kDimHead, e = j % kDimHead;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < kDimHead; ++d) acc = fmaf(cx[(h * kDimHead + d) * kDimHead + e], wq[(long long)(h * kDimHead + d) * C + k0 + kk], acc);
+    s_T[j][kk] = acc;
+  }
+  __syncthreads();
+  bool over = false;
+  for (int pi = threadIdx.x; pi < C * 4; pi += 256) {
+    const int n = pi >> 2, g4 = pi & 3;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    const float* w = wout + (long long)n * kHidden;
+    for (int j = 0; j < kHidden; ++j) {
+      const float wj = w[j];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = fmaf(wj, s_T[j][g4 * 8 + q], acc[q]);
+    }
+    float* base = wtotal + (long long)b * C * C;
+    if (f16) {
+      typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+      half8_t hi, lo;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        us_half h_, l_;
+        split_f16x3(acc[q], h_, l_, over);
+        hi[q] = h_;
+        lo[q] = l_;
+      }
+      _Float16* d = reinterpret_cast<_Float16*>(base) + (((long long)blockIdx.x * C + n) * 4 + g4) * 16;
+      *reinterpret_cast<half8_t*>(d) = hi;
+      *reinterpret_cast<half8_t*>(d + 8) = lo;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = k0 + g4 * 8 + q;
+        base[((long long)(k / bk) * C + n) * bk + k % bk] = acc[q];
+      }
+    }
+  }
+  if (f16) range_report(range_flag, over, kRangeWeight);
+}
+
+hipError_t launch_attn_wtotal(const float* ctx, const float* wout, const float* wq, float* wtotal, int B, int C, int bk, bool f16, hipStream_t s) {
+  if (C % 32 != 0 || (f16 && bk != 32) || bk <= 0 || C % bk != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_wtotal_kernel, dim3(C / 32, B), dim3(256), 0, s, ctx, wout, wq, wtotal, C, bk, f16 ? 1 : 0, current_range_flag());
+  return hipGetLastError();
+}
+
 // weff[b] in the conv kernel's packed layout [1 tap][128/bk][C][bk]:
 //   weff[co][h*32+d] = sum_e wout[co][h*32+e] * ctx[b][h][d][e]
 __global__ __launch_bounds__(256) void attn_weff_kernel(const float* __restrict__ ctx, const float* __restrict__ wout,

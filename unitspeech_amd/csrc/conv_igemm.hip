@@ -158,6 +158,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 
   unsigned aoff[IA];    // per-lane byte offset of the current tap's source row chunk (>= a_bytes: reads zeros)
   unsigned wtap_bytes = 0;
+  const int wrows = a.wt_rows ? a.wt_rows : a.Cout;      // rows per K-chunk of the packed weight (ConvArgs::wt_rows)
   auto setup_tap = [&](int tap) {
     const int dy = (int)((dy_bits >> (4 * tap)) & 15) - 8;
     const int dx = (int)((dx_bits >> (4 * tap)) & 15) - 8;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       if (a.debug & 32) aoff[j] = (unsigned)(j * 4096 + lane * 16) & 0xffff;      // every load hits one hot 64 KB window
 #endif
     }
-    wtap_bytes = (unsigned)wt_i * (unsigned)nchunk * (unsigned)a.Cout * (unsigned)(BK * 4);
+    wtap_bytes = (unsigned)wt_i * (unsigned)nchunk * (unsigned)wrows * (unsigned)(BK * 4);
 #ifdef US_CONV_ABLATE
     if (a.debug & 32) wtap_bytes = 0;
 #endif
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     float* As = smem + buf * BUF;
     float* Bs = As + TM * BK;
     unsigned ach = (unsigned)ch * (unsigned)(BK * 4);
-    unsigned wb = wtap_bytes + (unsigned)ch * (unsigned)a.Cout * (unsigned)(BK * 4);
+    unsigned wb = wtap_bytes + (unsigned)ch * (unsigned)wrows * (unsigned)(BK * 4);
 #ifdef US_CONV_ABLATE
     if (a.debug & 32) { ach = 0; wb = 0; }
 #endif
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
         else setup_tap(tap_n);
       }
       pend_ach = (unsigned)ch_n * (unsigned)(BK * 4);
-      pend_wb = wtap_bytes + (unsigned)ch_n * (unsigned)a.Cout * (unsigned)(BK * 4);
+      pend_wb = wtap_bytes + (unsigned)ch_n * (unsigned)wrows * (unsigned)(BK * 4);
     }
     float* As = smem + dma_buf * BUF;
     float* Bs = As + TM * BK;
@@ -694,13 +695,13 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // 1x1 convolutions and 11 % of the level-0 3x3s).
   __syncthreads();                                   // every wave is done with the operand buffers
   if constexpr (!WINO && MB == 1) {
-    if (a.attn_part_ctx && n0 >= TN) {
+    if (a.attn_part_ctx && n0 >= a.attn_q_cols) {
       // to_qkv column tiles 1 / 2: this wave's two 32-column blocks are k_h and v_h of head h for 32 of the tile's 64 rows
       // (qkv_src_row).  Linear attention (unitspeech/unitspeech.py:91-92): k = softmax over ALL n positions, ctx = k v^T; here the
       // online-softmax partial of the 64 rows: column maxima m, P = exp(k - m), s = sum_rows P, ctx = P^T v.  A 32x32 accumulator
       // block has its column on the lane and its rows in the registers, which is exactly the operand layout of
       // v_mfma_f32_32x32x2_f32 for a product that sums over ROWS: register r of P and of V go in as they stand.
-      const int h = (n0 / TN - 1) * 2 + wn;
+      const int h = ((n0 - a.attn_q_cols) / TN) * 2 + wn;
       float* xm = smem;                  // [wn][wm][32]  column maxima of each wave
       float* xs = smem + 128;            // [wn][32]      column sums of wave wm = 1
       float* xc = smem + 256;            // [wn][32][32]  ctx of wave wm = 1
@@ -1024,7 +1025,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   }
   if (a.attn_part_ctx) {
     // to_qkv with the attention reduction in the epilogue: three 128-column tiles, 64-row tiles (one chunk of partials each), one pass
-    if (a.Cout != 3 * kHidden || a.ntaps != 1 || a.istride != 1 || a.ostep != 1 || a.wino_out || a.nphase > 1 || a.bias || a.add || a.alpha ||
+    if (!((a.Cout == 3 * kHidden && a.attn_q_cols == kHidden) || (a.Cout == 2 * kHidden && a.attn_q_cols == 0)) || a.ntaps != 1 || a.istride != 1 || a.ostep != 1 || a.wino_out || a.nphase > 1 || a.bias || a.add || a.alpha ||
         a.stats || a.f16 == 1 || !a.attn_part_m || !a.attn_part_s || a.attn_nchunks != (a.Hs * a.Ws + 63) / 64)
       return hipErrorInvalidValue;
     tm = 64;

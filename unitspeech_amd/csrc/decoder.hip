@@ -30,6 +30,8 @@ struct DevBuf {
 
 enum class Kind { RAW, CONV_OIHW, CONVT_IOHW };
 
+constexpr int kWtotalMaxC = 256;
+
 struct Slot {
   std::string key;
   std::vector<int64_t> shape;
@@ -49,6 +51,7 @@ struct Slot {
   bool dg_as_1x1 = false;  // RAW [Cout][Cin][1][1] tensor that also needs a dgrad pack (attention to_out)
   bool is_qkv = false;     // attention to_qkv: a second forward pack with the rows in qkv_src_row() order (ConvArgs::attn_part_ctx)
   DevBuf qkv_rows;         // ... in the same operand form as `buf` (f16x3 planes or fp32)
+  DevBuf q_raw;            // ... and W_q = rows 0..127 in the reference layout [128][C] (launch_attn_wtotal)
   float* grad = nullptr; // caller-owned gradient buffer (reference layout) for the current backward call
   bool grad_unscaled = false;   // ... already multiplied by the inverse loss scale by the pass that wrote it (conv_wgrad's unpack)
   bool loaded = false;
@@ -120,6 +123,11 @@ struct us_decoder {
   int wgrad_side_streams = 1;
   std::vector<hipStream_t> wgrad_streams;
   std::vector<hipEvent_t> wgrad_events;
+  // attention with q folded away, out = x + g (W_total x + b_o) with W_total = W_out blockdiag(ctx^T) W_q (attention()): bit l = U-Net level l
+  // (C <= kWtotalMaxC only: the projection's K grows from 128 to C); US_ATTN_WTOTAL
+  // (measured at B = 1: level 0 only +0.9 %; level 0 and the 128-channel up level +0.6 %; levels 0-1 incl. the 256-channel one +0.0 %)
+  int attn_wtotal_levels = 0x1;
+  int attn_wtotal_max_c = 128;       // US_ATTN_WTOTAL_MAXC (<= kWtotalMaxC)
   bool fuse_final = true;    // US_FUSE_FINAL=0: the final Block's GroupNorm + Mish as its own launch before the 1x1 projection
   bool wino_narrow = false; // US_WINO_NARROW=1: Winograd also for convolutions with cout <= dim below level 0 (add_resnet)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
@@ -352,6 +360,7 @@ struct Buffers {
   std::vector<float*> D, P, Q, S1, S2, QKV, CAT;
   float* U0;
   float *part_ctx, *part_m, *part_s, *ctx, *weff, *colM, *colS, *ctx_split;
+  float* wtotal = nullptr;         // [Bp][C][C] W_out blockdiag(ctx^T) W_q of the levels whose attention folds q away (attention())
   float *wino_v = nullptr, *wino_m = nullptr;   // Winograd-domain input / product tensors [16][Bp][tiles][C]
   float* splitk = nullptr;         // split-K slab scratch of the conv kernel
   size_t splitk_floats = 0;
@@ -404,6 +413,7 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false
   b.splitk_floats = B * ((size_t)4 << 20);  // 4 Mi floats per item: the conv launcher's bound on its split-K slabs
   b.splitk = A.alloc<float>(b.splitk_floats);
   b.weff = A.alloc<float>(B * (size_t)max_c * kHidden);
+  if (!train && h->attn_wtotal_levels) b.wtotal = A.alloc<float>(B * (size_t)kWtotalMaxC * kWtotalMaxC);
   // Winograd scratch, sized from the convolutions that use it: V holds the conv's input channels and M its output channels;
   // the data gradient (training plans) swaps the two
   size_t wv = 0, wm = 0;
@@ -759,6 +769,36 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   int q_ld = 3 * kHidden;
   bool q_split = false;
   int nparts = nch;
+  if (e.h->attn_fuse && at.qkv.w->qkv_rows.p && at.qkv.w->q_raw.p && b.wtotal && ((e.h->attn_wtotal_levels >> l) & 1) && at.dim <= e.h->attn_wtotal_max_c &&
+      at.dim % 32 == 0) {
+    // q folded away: to_qkv computes k | v only, for the n-reduction in its epilogue, and stores nothing; then
+    // out = x + g (W_total x + b_o), W_total[b] = W_out blockdiag(ctx[b]^T) W_q: a C x C projection of x per item instead of q = W_q x written
+    // ([n][128]), read back and projected with K = 128 (a third less to_qkv work and 2 * n * 128 floats less traffic; worth it where C <= 256)
+    const int H = e.h->cfg.n_feats >> l, W = e.T >> l;
+    const int nch64 = (n + 63) / 64;
+    ConvArgs a = base_args(e, at.qkv, in, in_ld, H, W, qkv, kHidden, H, W);
+    a.Cout = 2 * kHidden;
+    a.wt_rows = 3 * kHidden;
+    // rows kHidden.. of every K-chunk of the qkv_src_row-ordered pack (per head k_h | v_h)
+    a.wt = at.qkv.w->qkv_rows.p + (size_t)kHidden * at.qkv.w->bk;
+    a.ntaps = 1;
+    a.set_tap(0, 0, 0, 0);
+    a.attn_part_ctx = b.part_ctx; a.attn_part_m = b.part_m; a.attn_part_s = b.part_s; a.attn_nchunks = nch64;
+    a.attn_q_cols = 0;
+    CK(run_conv(e, a));
+    const bool f16 = e.h->f16x3 && e.h->f16x3_direct;
+    CK(launch_attn_merge(b.part_ctx, b.part_m, b.part_s, e.Bp, nch64, b.ctx, b.colM, b.colS, b.ctx_split, at.out_w->buf.p, nullptr, at.dim,
+                         pick_bk(kHidden), f16, e.s));
+    const int bkc = pick_bk(at.dim);
+    CK(launch_attn_wtotal(b.ctx, at.out_w->buf.p, at.qkv.w->q_raw.p, b.wtotal, e.Bp, at.dim, bkc, f16, e.s));
+    ConvW tot;
+    tot.cin = at.dim; tot.cout = at.dim;
+    Slot tmp;             // only .bk / .buf / .direct_f16 are read by base_args
+    tmp.bk = bkc; tmp.buf.p = b.wtotal; tmp.direct_f16 = f16;
+    tot.w = &tmp; tot.b = nullptr;
+    return conv1x1(e, tot, in, in_ld, l, true, out, out_ld, in, in_ld, at.g->buf.p, b.wtotal, (long long)at.dim * at.dim, at.out_b->buf.p,
+                   false, out_split);
+  }
   if (e.h->attn_fuse && at.qkv.w->qkv_rows.p) {
     // to_qkv with the n-reduction in its epilogue: only q is written ([n][128]); chunks of 64 rows (ConvArgs::attn_part_ctx)
     const int H = e.h->cfg.n_feats >> l, W = e.T >> l;
@@ -769,6 +809,7 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
     a.ntaps = 1;
     a.set_tap(0, 0, 0, 0);
     a.attn_part_ctx = b.part_ctx; a.attn_part_m = b.part_m; a.attn_part_s = b.part_s; a.attn_nchunks = nch64;
+    a.attn_q_cols = kHidden;
     // q has one reader, the folded to_out convolution below: where that runs as f16x3 it takes q pre-split
     static int q_split_env = -1;                     // US_Q_SPLIT=0: q stays fp32 (A/B)
     if (q_split_env < 0) { const char* ev = getenv("US_Q_SPLIT"); q_split_env = ev ? atoi(ev) : 0; }      // measured: -0.4 % (K = 128: not split-bound)
@@ -1122,6 +1163,8 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   if (const char* wf = getenv("US_PRESPLIT")) h->presplit = atoi(wf) != 0;
   if (const char* wf = getenv("US_ATTN_FUSE")) h->attn_fuse = atoi(wf) != 0;
   if (const char* ff = getenv("US_FUSE_FINAL")) h->fuse_final = atoi(ff) != 0;
+  if (const char* aw = getenv("US_ATTN_WTOTAL")) h->attn_wtotal_levels = atoi(aw);
+  if (const char* aw = getenv("US_ATTN_WTOTAL_MAXC")) h->attn_wtotal_max_c = atoi(aw) > kWtotalMaxC ? kWtotalMaxC : atoi(aw);
   if (const char* ws = getenv("US_WGRAD_STREAM")) h->wgrad_side_streams = atoi(ws) < 0 ? 0 : (atoi(ws) > Tape::kSideMax ? Tape::kSideMax : atoi(ws));
   if (flags & US_CREATE_EXACT_FP32) h->f16x3 = false;
   h->exact = !h->f16x3;
@@ -1156,6 +1199,8 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
     if (ok && s->is_qkv) {
       s->qkv_rows.n = s->buf.n;
       ok = hipMalloc(reinterpret_cast<void**>(&s->qkv_rows.p), s->qkv_rows.n * sizeof(float)) == hipSuccess;
+      s->q_raw.n = (size_t)kHidden * s->shape[1];
+      ok = ok && hipMalloc(reinterpret_cast<void**>(&s->q_raw.p), s->q_raw.n * sizeof(float)) == hipSuccess;
     }
     if (ok && s->want_wino) {
       s->wino.n = s->wino_dg.n = (size_t)16 * s->shape[0] * s->shape[1];
@@ -1177,7 +1222,7 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
     }
     if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); if (t->qkv_rows.p) (void)hipFree(t->qkv_rows.p); }
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); if (t->qkv_rows.p) (void)hipFree(t->qkv_rows.p); if (t->q_raw.p) (void)hipFree(t->q_raw.p); }
       return US_EHIP;
     }
   }
@@ -1205,7 +1250,7 @@ int us_decoder_flush_weights(us_handle h, us_stream stream) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); if (s->qkv_rows.p) (void)hipFree(s->qkv_rows.p); }
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); if (s->qkv_rows.p) (void)hipFree(s->qkv_rows.p); if (s->q_raw.p) (void)hipFree(s->q_raw.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   if (h->copy_tab_dev) (void)hipFree(h->copy_tab_dev);
   if (h->grad_tab_dev) (void)hipFree(h->grad_tab_dev);
@@ -1281,6 +1326,12 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
       else if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
       else if (s->direct_f16) conv_f16(s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true);
       else US_HIP(h, launch_pack_conv_weight(data, s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true, s->bk, st));
+      if (s->q_raw.p) {       // rows 0..127 of [384][C][1][1]: the tensor's first 128 * C floats, through the deferred copy table
+        bool replaced = false;
+        for (auto& pc : h->pending_copies)
+          if (pc.dst == s->q_raw.p) { pc.src = data; replaced = true; break; }
+        if (!replaced) h->pending_copies.push_back(CopyEnt{data, s->q_raw.p, (long long)s->q_raw.n});
+      }
       if (s->qkv_rows.p && s->direct_f16) conv_f16(s->qkv_rows.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, true);
       else if (s->qkv_rows.p) US_HIP(h, launch_pack_conv_weight(data, s->qkv_rows.p, (int)s->shape[0], (int)s->shape[1], 1, 1, true, s->bk, st, true));
       if (s->wino_dg.p && s->wino_dg_f16) wino_f16(s->wino_dg.p, true);

@@ -119,6 +119,9 @@ struct ConvArgs {
   float* attn_part_m;    // [B][attn_nchunks][128]
   float* attn_part_s;    // [B][attn_nchunks][128]
   int attn_nchunks;      // ceil(Hs * Ws / 64)
+  int attn_q_cols;       // kHidden: column tile 0 is q and is stored; 0: the launch computes k | v only (Cout = 2 * kHidden, nothing stored:
+                         // the caller folds W_q into the output projection, launch_attn_wtotal)
+  int wt_rows;           // rows per K-chunk of the packed weight when the launch uses only Cout of them (0: Cout)
 #ifdef US_STAMP
   unsigned long long* stamp_out;   // diagnostic build only: per (workgroup, wave) {cycles at the vmcnt wait, at the barrier, in the body, steps}
 #endif
@@ -226,6 +229,9 @@ constexpr int kAttnMaxSplit = 16;
 hipError_t launch_attn_ctx_finalize(const float* part_ctx, const float* part_m, const float* part_s, int B, int nchunks,
                                     float* ctx, float* colM, float* colS, float* split_ws, hipStream_t s);
 // f16 = true (bk = 32): weff as two interleaved fp16 planes per value, for the f16x3 form of the folded to_out convolution
+// W_total[b] = W_out blockdiag(ctx[b]^T) W_q  ([C][C]; the attention's q never exists: out = x + g (W_total x + b_o)), stored in the conv kernel's
+// packed layout for K = N = C (f16: two-plane form, bk 32; else fp32 [C/bk][C][bk]).  wq: rows 0..127 of to_qkv's weight, [128][C].
+hipError_t launch_attn_wtotal(const float* ctx, const float* wout, const float* wq, float* wtotal, int B, int C, int bk, bool f16, hipStream_t s);
 hipError_t launch_attn_weff(const float* ctx, const float* wout /*[C][128]*/, float* weff, int B, int C, int bk, hipStream_t s,
                             bool f16 = false);
 // The same merge in two launches (ranges of chunks with their own maxima, then the ranges), with the fold of ctx into to_out's weights
