@@ -13,6 +13,7 @@
 namespace us {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kChunk = 128;
 constexpr int kQkvLd = 3 * kHidden;
@@ -313,58 +314,73 @@ hipError_t launch_attn_merge(const float* part_ctx, const float* part_m, const f
 __global__ __launch_bounds__(256) void attn_wtotal_kernel(const float* __restrict__ ctx, const float* __restrict__ wout,
                                                           const float* __restrict__ wq, float* __restrict__ wtotal, int C, int bk, int f16,
                                                           unsigned* range_flag) {
-  __shared__ float s_T[kHidden][33];
-  const int b = blockIdx.y, k0 = blockIdx.x * 32;
+  // grid (k tile of 32, item, n tile of 32): every block re-derives its k tile of T (131 K multiply-adds) and stages its 32 rows of W_out.
+  // All operands go through LDS first (coalesced loads), rows padded to 36 floats so that 4 consecutive k are one 16-byte read.
+  __shared__ __attribute__((aligned(16))) float s_T[kHidden][36];
+  __shared__ float s_C[kHidden][33];                                      // ctx[b] as [h*32 + d][e]
+  __shared__ __attribute__((aligned(16))) float s_QW[kHidden * 36];       // W_q's k tile [h*32 + d][kk]; after T: 32 rows of W_out [nl][j] (ld 129)
+  const int b = blockIdx.y, k0 = blockIdx.x * 32, n0 = blockIdx.z * 32;
   const float* cx = ctx + (long long)b * kHeads * kDimHead * kDimHead;
   for (int i = threadIdx.x; i < kHidden * 32; i += 256) {
-    const int j = i >> 5, kk = i & 31;
-    const int h = j / kDimHead, e = j % kDimHead;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < kDimHead; ++d) acc = fmaf(cx[(h * kDimHead + d) * kDimHead + e], wq[(long long)(h * kDimHead + d) * C + k0 + kk], acc);
-    s_T[j][kk] = acc;
+    s_C[i >> 5][i & 31] = cx[i];
+    s_QW[(i >> 5) * 36 + (i & 31)] = wq[(long long)(i >> 5) * C + k0 + (i & 31)];
   }
   __syncthreads();
-  bool over = false;
-  for (int pi = threadIdx.x; pi < C * 4; pi += 256) {
-    const int n = pi >> 2, g4 = pi & 3;
-    float acc[8];
+  for (int i = threadIdx.x; i < kHidden * 8; i += 256) {        // (j, group of 4 k)
+    const int j = i >> 3, k4 = (i & 7) * 4;
+    const int h = j / kDimHead, e = j % kDimHead;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    const float* w = wout + (long long)n * kHidden;
-    for (int j = 0; j < kHidden; ++j) {
-      const float wj = w[j];
+    for (int d = 0; d < kDimHead; ++d) {
+      const float c = s_C[h * kDimHead + d][e];
+      const f32x4 q = *reinterpret_cast<const f32x4*>(&s_QW[(h * kDimHead + d) * 36 + k4]);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] = fmaf(wj, s_T[j][g4 * 8 + q], acc[q]);
+      for (int t = 0; t < 4; ++t) acc[t] = fmaf(c, q[t], acc[t]);
     }
-    float* base = wtotal + (long long)b * C * C;
-    if (f16) {
-      typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-      half8_t hi, lo;
+    *reinterpret_cast<f32x4*>(&s_T[j][k4]) = acc;
+  }
+  __syncthreads();
+  float* s_W = s_QW;                                               // 32 * 129 <= 128 * 36 floats
+  for (int i = threadIdx.x; i < 32 * kHidden; i += 256) s_W[(i / kHidden) * (kHidden + 1) + i % kHidden] = wout[(long long)(n0 + i / kHidden) * kHidden + i % kHidden];
+  __syncthreads();
+  bool over = false;
+  const int nl = threadIdx.x >> 3, g8 = threadIdx.x & 7;          // one output channel, 4 consecutive k
+  const int n = n0 + nl;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < kHidden; ++j) {
+    const float wj = s_W[nl * (kHidden + 1) + j];
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(&s_T[j][g8 * 4]);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        us_half h_, l_;
-        split_f16x3(acc[q], h_, l_, over);
-        hi[q] = h_;
-        lo[q] = l_;
-      }
-      _Float16* d = reinterpret_cast<_Float16*>(base) + (((long long)blockIdx.x * C + n) * 4 + g4) * 16;
-      *reinterpret_cast<half8_t*>(d) = hi;
-      *reinterpret_cast<half8_t*>(d + 8) = lo;
-    } else {
+    for (int t = 0; t < 4; ++t) acc[t] = fmaf(wj, tv[t], acc[t]);
+  }
+  float* base = wtotal + (long long)b * C * C;
+  if (f16) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    half4_t hi, lo;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = k0 + g4 * 8 + q;
-        base[((long long)(k / bk) * C + n) * bk + k % bk] = acc[q];
-      }
+    for (int t = 0; t < 4; ++t) {
+      us_half h_, l_;
+      split_f16x3(acc[t], h_, l_, over);
+      hi[t] = h_;
+      lo[t] = l_;
+    }
+    // piece (k tile, n, group of 8 k) = 8 hi | 8 lo halves; this thread owns half of each plane
+    _Float16* d = reinterpret_cast<_Float16*>(base) + (((long long)blockIdx.x * C + n) * 4 + (g8 >> 1)) * 16 + (g8 & 1) * 4;
+    *reinterpret_cast<half4_t*>(d) = hi;
+    *reinterpret_cast<half4_t*>(d + 8) = lo;
+    range_report(range_flag, over, kRangeWeight);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = k0 + g8 * 4 + t;
+      base[((long long)(k / bk) * C + n) * bk + k % bk] = acc[t];
     }
   }
-  if (f16) range_report(range_flag, over, kRangeWeight);
 }
 
 hipError_t launch_attn_wtotal(const float* ctx, const float* wout, const float* wq, float* wtotal, int B, int C, int bk, bool f16, hipStream_t s) {
   if (C % 32 != 0 || (f16 && bk != 32) || bk <= 0 || C % bk != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(attn_wtotal_kernel, dim3(C / 32, B), dim3(256), 0, s, ctx, wout, wq, wtotal, C, bk, f16 ? 1 : 0, current_range_flag());
+  hipLaunchKernelGGL(attn_wtotal_kernel, dim3(C / 32, B, C / 32), dim3(256), 0, s, ctx, wout, wq, wtotal, C, bk, f16 ? 1 : 0, current_range_flag());
   return hipGetLastError();
 }
 
