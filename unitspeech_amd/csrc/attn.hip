@@ -206,7 +206,7 @@ __global__ __launch_bounds__(1024) void attn_merge_kernel(const float* __restric
   __syncthreads();
   // ctx_r[d][e]: thread (d, e) walks the chunks; the weights exp(m_c[d] - M_r[d]) of 64 chunks at a time come from LDS
   const float Md = s_M[d];
-  float acc0 = 0.f, acc1 = 0.f;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
   for (int base = lo; base < hi; base += 64) {
     const int nb = min(64, hi - base);
     __syncthreads();
@@ -215,16 +215,22 @@ __global__ __launch_bounds__(1024) void attn_merge_kernel(const float* __restric
       s_m[c][col] = expf(pm[(long long)(base + c) * kHidden + col] - s_M[col]);
     }
     __syncthreads();
+    // eight independent loads in flight per thread (each chunk's value is 4 KB from the next: the loop is latency, not bandwidth)
     int c = 0;
-    for (; c + 2 <= nb; c += 2) {
-      acc0 = fmaf(s_m[c][d], pc[(long long)(base + c) * kHeads * 1024], acc0);
-      acc1 = fmaf(s_m[c + 1][d], pc[(long long)(base + c + 1) * kHeads * 1024], acc1);
+    for (; c + 8 <= nb; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pc[(long long)(base + c + u) * kHeads * 1024];
+      acc0 = fmaf(s_m[c][d], v[0], acc0);     acc1 = fmaf(s_m[c + 1][d], v[1], acc1);
+      acc2 = fmaf(s_m[c + 2][d], v[2], acc2); acc3 = fmaf(s_m[c + 3][d], v[3], acc3);
+      acc0 = fmaf(s_m[c + 4][d], v[4], acc0); acc1 = fmaf(s_m[c + 5][d], v[5], acc1);
+      acc2 = fmaf(s_m[c + 6][d], v[6], acc2); acc3 = fmaf(s_m[c + 7][d], v[7], acc3);
     }
-    if (c < nb) acc0 = fmaf(s_m[c][d], pc[(long long)(base + c) * kHeads * 1024], acc0);
+    for (; c < nb; ++c) acc0 = fmaf(s_m[c][d], pc[(long long)(base + c) * kHeads * 1024], acc0);
   }
   (void)Md;
   const long long o = ((long long)blockIdx.x * gridDim.y + bh);
-  r_ctx[o * 1024 + d * kDimHead + e] = acc0 + acc1;
+  r_ctx[o * 1024 + d * kDimHead + e] = (acc0 + acc1) + (acc2 + acc3);
   if (d == 0) { r_m[o * kDimHead + e] = s_M[e]; r_s[o * kDimHead + e] = s_S[e]; }
 }
 
@@ -267,8 +273,15 @@ __global__ __launch_bounds__(1024) void attn_final_kernel(const float* __restric
   const int dd = threadIdx.x & 31;
   bool over = false;
   const int co_end = min(C, ((int)blockIdx.y + 1) * 128);
+  // this head's 32 columns of the tile's 128 rows of W_out through LDS (one coalesced pass instead of 32 dependent loads per output)
+  __shared__ float s_wo[128][kDimHead + 1];
+  for (int i = threadIdx.x; i < 128 * kDimHead; i += 1024) {
+    const int r = i >> 5, k = i & 31, co = blockIdx.y * 128 + r;
+    s_wo[r][k] = co < C ? wout[(long long)co * kHidden + h * kDimHead + k] : 0.f;
+  }
+  __syncthreads();
   for (int co = blockIdx.y * 128 + (threadIdx.x >> 5); co < co_end; co += 32) {
-    const float* w = wout + (long long)co * kHidden + h * kDimHead;
+    const float* w = s_wo[co - blockIdx.y * 128];
     float a2 = 0.f;
 #pragma unroll
     for (int k = 0; k < kDimHead; ++k) a2 = fmaf(w[k], s_ctx[dd][k], a2);
