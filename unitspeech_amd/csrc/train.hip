@@ -19,12 +19,14 @@ __device__ __forceinline__ float wsum(float v) {
 }
 
 // d/dz [ z * tanh(softplus(z)) ]  (softplus threshold 20 as in the forward)
+// v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), as mish_f of the forward (ops.hip): with the library expf and two IEEE divisions the
+// GroupNorm backward ran at a fifth of the HBM rate (15 ms of the 61 ms pre-training step)
 __device__ __forceinline__ float mish_grad(float z) {
   if (z > 20.f) return 1.f;
-  float w = expf(z);
+  float w = __expf(z);
   float u = w * (w + 2.f);
-  float th = u / (u + 2.f);                 // tanh(softplus(z))
-  float sg = w / (1.f + w);                 // sigmoid(z) = d softplus / dz
+  float th = u * __frcp_rn(u + 2.f);        // tanh(softplus(z))
+  float sg = w * __frcp_rn(1.f + w);        // sigmoid(z) = d softplus / dz
   return th + z * (1.f - th * th) * sg;
 }
 
@@ -584,6 +586,7 @@ __device__ __forceinline__ GnStat gn_stat(const double* stats, long long b, int 
 // A thread owns one channel quad for its whole life (C/4 divides 256 or is a multiple of it for every width of the U-Net; any
 // other width takes the re-derive-per-element branch), reads 16 bytes per operand and keeps its per-channel and per-group sums
 // in registers: one round of LDS atomics per thread at the end instead of two per element.
+constexpr int kGnFlush = 16;
 template <int PASS>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   const int b = blockIdx.y;
@@ -618,7 +621,10 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   int c = (int)(i % C4) * 4;
   f32x4 ga, be, mean4, rstd4, s14, s24;
   f32x4 ch0 = {0.f, 0.f, 0.f, 0.f}, ch1 = {0.f, 0.f, 0.f, 0.f};    // PASS 1: (sum dz*xn, sum dz); PASS 2: (sum gy, -)
-  double g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
+  // group sums of this thread: fp32 over at most kGnFlush elements, then into the fp64 LDS accumulators (the fp64 adds per element were
+  // as expensive as the rest of the pass)
+  float g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
+  int since_flush = 0;
   float gy_max = 0.f;              // PASS 2: max |gy| of this thread (the f16x3 weight-gradient kernel scales gy by it: WgradArgs::gy_amax)
   int cur = -1;
   auto flush = [&]() {
@@ -628,9 +634,9 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
       atomicAdd(&s_ch[0][cur + k], ch0[k]);
       if (PASS == 1) {
         atomicAdd(&s_ch[1][cur + k], ch1[k]);
-        atomicAdd(&s_grp[(cur + k) / cg][0], g1[k]);
-        atomicAdd(&s_grp[(cur + k) / cg][1], g2[k]);
-        g1[k] = g2[k] = 0.0;
+        atomicAdd(&s_grp[(cur + k) / cg][0], (double)g1[k]);
+        atomicAdd(&s_grp[(cur + k) / cg][1], (double)g2[k]);
+        g1[k] = g2[k] = 0.f;
       }
       ch0[k] = ch1[k] = 0.f;
     }
@@ -672,8 +678,8 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
       if (PASS == 1) {
         ch0[k] += dz * xn;
         ch1[k] += dz;
-        g1[k] += (double)(dz * ga[k]);
-        g2[k] += (double)(dz * ga[k] * xn);
+        g1[k] += dz * ga[k];
+        g2[k] += dz * ga[k] * xn;
       } else {
         o[k] = rstd4[k] * (dz * ga[k] - s14[k] - xn * s24[k]);
         ch0[k] += o[k];
@@ -681,6 +687,12 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
       }
     }
     if (PASS == 2) *reinterpret_cast<f32x4*>(ob + p * a.gy_ld + c) = o;
+    if (PASS == 1 && ++since_flush == kGnFlush) {      // (one thread rarely gets this far: 4-10 elements per quad at training sizes)
+      const int keep = cur;
+      flush();
+      cur = keep;
+      since_flush = 0;
+    }
     if (fixed_quad) {
       p += rpi;
       w += wstep;
@@ -713,6 +725,17 @@ hipError_t launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
   int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
+  // every block ends with one atomic per channel on the SAME C addresses (gamma / beta / conv-bias gradients), which the L2 serialises:
+  // at 32 crops, 14,080 blocks of a level-0 launch queued 28,000 atomics per address.  Cap the blocks of a launch (all items) instead.
+  // (measured: pre-training step at 32 crops 62.1 ms uncapped, 55.1-55.8 for caps of 256 ... 1,024 blocks; one crop: 10.28 -> 10.15 ms
+  // per fine-tune iteration at 256)
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("US_GN_BWD_BLOCKS"); target = e ? atoi(e) : 512; }
+  if (target > 0) {
+    if (blocks > target / 2) blocks = target / 2;
+    if ((long long)blocks * a.B > target) blocks = target / a.B;
+    if (blocks < 8) blocks = 8;
+  }
   hipLaunchKernelGGL(gn_bwd_kernel<1>, dim3(blocks, a.B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(gn_bwd_kernel<2>, dim3(blocks, a.B), dim3(256), 0, s, a);
   return hipGetLastError();
