@@ -917,15 +917,22 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
   const float* mb = mask + (long long)(b % mask_bmod) * mask_ld;
   const long long total = n * C;
   float gbacc = 0.f;
+  // a thread keeps its channel when the grid stride is a multiple of C (every full-size launch): its products are summed in a register
+  // and reach the LDS accumulator once
+  const bool fixed_c = ((long long)gridDim.x * 256) % C == 0;
+  float wacc = 0.f;
+  int c_mine = -1;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long long p = i / C;
     const float g = go[(long long)b * n + p] * mb[(int)(p % W)];
     const long long idx = ((long long)b * n + p) * ld + c;
-    atomicAdd(&s_w[c], g * h[idx]);
+    if (fixed_c) { wacc += g * h[idx]; c_mine = c; }
+    else atomicAdd(&s_w[c], g * h[idx]);
     gh[idx] = g * w[c];
     if (c == 0) gbacc += g;
   }
+  if (fixed_c && c_mine >= 0) atomicAdd(&s_w[c_mine], wacc);
   gbacc = wsum(gbacc);
   if ((threadIdx.x & 63) == 0 && gbacc != 0.f) atomicAdd(gb0, gbacc);
   __syncthreads();
@@ -939,6 +946,9 @@ hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float
   int blocks = (int)((n * C + 256 * 16 - 1) / (256 * 16));
   if (blocks < 1) blocks = 1;
   if (blocks > 512) blocks = 512;
+  // every block ends with C atomics on the same C addresses of gw (and one on gb0): cap the launch at 512 blocks over all items, as the
+  // GroupNorm backward (launch_gn_bwd)
+  if ((long long)blocks * B > 512) blocks = 512 / B < 4 ? 4 : 512 / B;
   hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks, B), dim3(256), 0, s, go, h, ld, w, mask, mask_ld, mask_bmod, W, n, C, gh, gw, gb0);
   return hipGetLastError();
 }
