@@ -157,6 +157,9 @@ int us_estimator_backward(us_handle h, uint64_t tape_id, const float* grad_out, 
                           us_stream stream);
 /* Drop a tape whose backward will never run (its workspace may then be reused). */
 int us_tape_release(us_handle h, uint64_t tape_id);
+/* 1 when us_estimator_backward OVERWRITES every element of this key's gradient buffer (the convolution weights: 99.9 % of the gradient
+ * bytes), so the buffer needs no zero-fill under US_BACKWARD_GRADS_ZEROED; 0 when the backward accumulates into it; -1: unknown key. */
+int us_grad_is_overwritten(us_handle h, const char* key);
 
 /* ---- elementwise steps of the training objective (no handle) -------------------------------------------------------
  * `forward_diffusion(x0, mask, t)` (unitspeech/unitspeech.py:376-384) with the gaussian draw z passed in:

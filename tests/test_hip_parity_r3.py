@@ -325,3 +325,43 @@ def test_weight_gradient_chains_on_the_second_stream_give_the_gradients_of_the_o
     _, again = _hip_grads(sd_np, *args)     # a second two-stream handle: same result again
     w2, _, worst2 = _rel(again, one)
     assert w2 <= 2e-7 and worst2 <= 1e-4
+
+
+def test_backward_needs_no_zero_fill_for_the_convolution_weight_gradients(sd_np):
+    """The gradient blob of a backward call is torch.empty: only its head (the tensors the library accumulates into) is zero-filled, the
+    convolution weights behind it are overwritten element by element (us_grad_is_overwritten).  The blob of the second call below is the
+    allocator block a NaN-filled tensor of the same size has just returned: every gradient must come out finite and equal to the first
+    call's."""
+    args = _crops(1, 176, key=71)
+    x0, mask, cond, spk, t, z = args
+    m = build(sd_np, train=True)
+    eng = m._get_engine()
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        with _ReplayRandn([z.to(DEV)]):
+            loss, _ = m.loss_t(x0.to(DEV), mask.to(DEV), cond.to(DEV), t.to(DEV), spk.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
+
+    ref = run()
+    n = eng.last_grad_blob.numel()
+    keys = [k for k in eng.grad_overwritten.__self__.__dict__["_grad_over"]][0]
+    flags = eng.grad_overwritten(keys)
+    over = [k for k, f in zip(keys, flags) if f]
+    assert len(over) == 52                                            # 44 ResnetBlock / final convolutions and res_convs, 8 to_qkv, 6 down / up -- minus the 2-channel first block's
+    assert all(k.endswith(".weight") for k in over)
+    assert not any(k.endswith(".bias") or ".mlp." in k or ".block.1." in k or k.endswith(".g") for k in over)
+    for p in m.parameters():
+        p.grad = None
+    eng.last_grad_blob = None
+    poison = torch.full((n,), float("nan"), device=DEV)
+    ptr = poison.data_ptr()
+    del poison
+    new = run()
+    assert eng.last_grad_blob.data_ptr() == ptr, "the caching allocator did not hand the poisoned block back: the test proves nothing"
+    assert all(torch.isfinite(g).all() for g in new.values())
+    whole, _, worst = _rel(new, ref)
+    assert whole <= 2e-7 and worst <= 1e-4

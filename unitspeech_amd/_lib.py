@@ -58,6 +58,7 @@ SIGNATURES = {
     "us_estimator_backward": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "us_tape_release": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "us_grad_is_overwritten": (C.c_int, [C.c_void_p, C.c_char_p]),
     "us_forward_diffusion": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "us_diffusion_loss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "us_diffusion_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),

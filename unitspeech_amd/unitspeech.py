@@ -250,6 +250,20 @@ class _Engine:
             raise RangeError(f"f16x3 range status {st}: a tensor beyond +-65504 reached a split-precision GEMM of a training call; "
                              "its results are non-finite.  Re-run with UNITSPEECH_EXACT=1 (model.exact = True)")
 
+    def grad_overwritten(self, keys):
+        """Per key: does us_estimator_backward overwrite (True) or accumulate into (False) its gradient buffer?  Cached per key tuple."""
+        cache = self.__dict__.setdefault("_grad_over", {})
+        k = tuple(keys)
+        if k not in cache:
+            flags = []
+            for key in k:
+                r = self.lib.us_grad_is_overwritten(self.handle, key.encode())
+                if r < 0:
+                    raise KeyError(f"us_grad_is_overwritten: unknown key {key!r}")
+                flags.append(bool(r))
+            cache[k] = flags
+        return cache[k]
+
     def get_workspace(self, nbytes: int, device) -> torch.Tensor:
         if self.workspace is None or self.workspace.numel() < nbytes or self.workspace.device != device:
             self.workspace = None
@@ -307,13 +321,21 @@ class _EstimatorFn(torch.autograd.Function):
         g = _f32c(grad_out, dev)
         # (the library scales g by an exact, data-driven power of two for its split-precision GEMMs and scales everything it returns
         # back: include/unitspeech_hip.h, us_estimator_backward)
-        # one zero-filled blob, one view per parameter: a single fill instead of one per tensor
+        # one blob, one view per parameter.  The tensors the backward accumulates into (norms, biases, MLPs, ...: 0.1 % of the bytes) sit
+        # at its head and are zero-filled with one launch; the convolution weights behind them are overwritten element by element
+        # (us_grad_is_overwritten) and need no fill: 476 MB less written per call
         sizes = [int(torch.Size(shape).numel()) for shape, _ in ctx.param_meta]
-        offs, total = [], 0
-        for sz in sizes:
-            offs.append(total)
-            total += (sz + 63) // 64 * 64          # keep every view 256-byte aligned
-        blob = torch.zeros(total, dtype=torch.float32, device=dev)
+        over = eng.grad_overwritten(keys)
+        offs, total = [0] * len(sizes), 0
+        for want in (False, True):
+            for i, sz in enumerate(sizes):
+                if over[i] == want:
+                    offs[i] = total
+                    total += (sz + 63) // 64 * 64  # keep every view 256-byte aligned
+            if not want:
+                head = total
+        blob = torch.empty(total, dtype=torch.float32, device=dev)
+        blob[:head].zero_()
         grads = [blob[o:o + sz].view(shape) for o, sz, (shape, _) in zip(offs, sizes, ctx.param_meta)]
         n = len(keys)
         ckeys = (C.c_char_p * n)(*[k.encode() for k in keys])
