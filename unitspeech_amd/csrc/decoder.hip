@@ -720,7 +720,7 @@ hipError_t resnet(EvalCtx& e, const ResnetW& r, const float* in, int in_ld, floa
   if (r.c2.w->wino.p && b.wino_v && e.h->wino_fuse_gn && gn_wino_input_supported(r.cout)) {
     // block1's GroupNorm + Mish + time embedding (pre-masked for block2's `x * mask`, :54) evaluated inside the Winograd input
     // transform of block2's conv: h1 is never written
-    WinoGnArgs g;
+    WinoGnArgs g{};
     g.stats = st1; g.gamma = r.g1->buf.p; g.beta = r.b1->buf.p; g.temb = tproj;
     g.mask = e.mask; g.mask_ld = e.T; g.mask_step = 1 << l; g.mask_bmod = e.Bm;
     CK(conv3x3_wino(e, r.c2, S1, r.cout, l, S2, r.cout, st2, &g));
@@ -921,7 +921,7 @@ hipError_t estimator_eval_impl(EvalCtx& e, const float* x, int Bx, const float* 
       // (the block's 1x1 res_conv output is not stored: its GroupNorm pass below re-evaluates it from the two input channels)
       CK(launch_first_conv(b.in2, r.c1.w->buf.p, r.c1.b->buf.p, r.res.w->buf.p, r.res.b->buf.p, b.S1[0], nullptr, st1, e.Bp, F, T, c, e.s));
       if (r.c2.w->wino.p && b.wino_v && h->wino_fuse_gn && gn_wino_input_supported(c)) {
-        WinoGnArgs g;       // as in resnet(): block1's GroupNorm + Mish + time embedding inside block2's input transform
+        WinoGnArgs g{};     // as in resnet(): block1's GroupNorm + Mish + time embedding inside block2's input transform
         g.stats = st1; g.gamma = r.g1->buf.p; g.beta = r.b1->buf.p; g.temb = b.tproj + b.tproj_off[r.index];
         g.mask = e.mask; g.mask_ld = e.T; g.mask_step = 1; g.mask_bmod = e.Bm;
         CK(conv3x3_wino(e, r.c2, b.S1[0], c, 0, b.S2[0], c, st2, &g));

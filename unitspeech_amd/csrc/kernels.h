@@ -375,6 +375,7 @@ struct WinoGnArgs {
   const float *gamma, *beta, *temb;    // temb: [B][C] or null
   const float* mask; int mask_ld, mask_step, mask_bmod;
   unsigned* range_flag;                // set by the launcher
+  float* h_out;                        // optional [B][H][W][C]: the activation d itself is stored too (training keeps h1 for the weight gradient)
 };
 bool gn_wino_input_supported(int C);
 hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, int C, const WinoGnArgs& g, hipStream_t s, bool split = false);

@@ -157,6 +157,9 @@ __global__ __launch_bounds__(256) void gn_wino_input_kernel(const float* __restr
       for (int k = 0; k < 4; ++k) v[k] = (gw_mish(raw[k] * s_sc[4 * q + k] + s_sh[4 * q + k]) * m + s_te[4 * q + k]) * m;
     }
     *reinterpret_cast<f32x4*>(patch + px * kGwLd + 4 * q) = v;
+    // the patch's interior (its tiles' own 2 x 2 pixels) belongs to this workgroup alone: the activation is stored from here
+    if (g.h_out && pr >= 1 && pr <= kGwPR - 2 && pc >= 1 && pc <= kGwPC - 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      *reinterpret_cast<f32x4*>(g.h_out + (((long long)b * H + iy) * W + ix) * C + c0 + 4 * q) = v;
   }
   __syncthreads();
   const int q = threadIdx.x % (kGwCS / 4), t = threadIdx.x / (kGwCS / 4);
