@@ -141,6 +141,8 @@ struct us_decoder {
   // us_estimator_backward: {2^k, 2^-k} of the gradient entering the pass, and the table of everything it returns (scaled back in one launch)
   float* grad_scale = nullptr;
   CopyEnt* grad_tab_dev = nullptr;
+  static constexpr size_t kLinJobs = 64;
+  LinJob *lin_tab_dev = nullptr, *lin_tab_bwd_dev = nullptr;   // job tables of the batched time projections (forward / backward)
   // RAW tensors (biases, GroupNorm affine, MLP weights: ~130 small ones) are copied by ONE table-driven launch per weight sync
   // instead of one hipMemcpyAsync each (fine-tuning re-loads every tensor after every optimiser step)
   std::vector<CopyEnt> pending_copies;
@@ -836,6 +838,27 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
                  at.out_b->buf.p, q_split, out_split);
 }
 
+int upload_bytes(us_decoder* h, const void* src, size_t nbytes, void* dev, hipStream_t st);
+
+// the ResnetBlocks' time projections as LinJobs in execution order (kernels.h); out / gy / gW / gb are filled by the caller
+inline int proj_jobs(us_decoder* h, std::vector<LinJob>& jobs, std::vector<const ResnetW*>& blocks) {
+  jobs.clear();
+  blocks.clear();
+  int o0 = 0;
+  auto add = [&](const ResnetW& r) {
+    LinJob j;
+    memset(&j, 0, sizeof j);
+    j.W = r.mlp_w->buf.p; j.bias = r.mlp_b->buf.p; j.o0 = o0; j.cout = r.cout; j.out_ld = r.cout;
+    jobs.push_back(j);
+    blocks.push_back(&r);
+    o0 += r.cout;
+  };
+  for (auto& d : h->downs) { add(d.r1); add(d.r2); }
+  add(h->mid1); add(h->mid2);
+  for (auto& u : h->ups) { add(u.r1); add(u.r2); }
+  return o0;
+}
+
 hipError_t time_embedding(EvalCtx& e, const float* t, const float* spk) {
   us_decoder* h = e.h;
   Buffers& b = *e.b;
@@ -844,6 +867,15 @@ hipError_t time_embedding(EvalCtx& e, const float* t, const float* spk) {
   CK(launch_linear(b.posemb, dim, h->mlp0_w->buf.p, h->mlp0_b->buf.p, b.mlp_h, 4 * dim, e.Bp, dim, 4 * dim, false, e.s));
   CK(launch_linear(b.mlp_h, 4 * dim, h->mlp2_w->buf.p, h->mlp2_b->buf.p, b.temb, td, e.Bp, 4 * dim, dim, true, e.s));
   CK(launch_copy_rows(spk, S, e.Bp, b.temb + dim, td, e.Bp, S, e.s));
+  // the 22 projections mlp(temb) of the ResnetBlocks (unitspeech.py:61,72) share their input: one launch from a job table
+  std::vector<LinJob> jobs;
+  std::vector<const ResnetW*> blocks;
+  const int total = proj_jobs(h, jobs, blocks);
+  if (h->lin_tab_dev && jobs.size() <= us_decoder::kLinJobs) {
+    for (size_t i = 0; i < jobs.size(); ++i) jobs[i].out = b.tproj + b.tproj_off[blocks[i]->index];
+    if (upload_bytes(h, jobs.data(), jobs.size() * sizeof(LinJob), h->lin_tab_dev, e.s) != US_OK) return hipErrorUnknown;
+    return launch_linear_multi(h->lin_tab_dev, (int)jobs.size(), total, b.temb, td, e.Bp, td, true, e.s);
+  }
   auto proj = [&](const ResnetW& r) {
     return launch_linear(b.temb, td, r.mlp_w->buf.p, r.mlp_b->buf.p, b.tproj + b.tproj_off[r.index], r.cout, e.Bp, td, r.cout, true,
                          e.s);
@@ -1233,6 +1265,8 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   }
   bool tab_ok = hipMalloc(reinterpret_cast<void**>(&h->copy_tab_dev), us_decoder::kStageBytes) == hipSuccess &&
                 hipMalloc(reinterpret_cast<void**>(&h->grad_tab_dev), us_decoder::kStageBytes) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void**>(&h->lin_tab_dev), us_decoder::kLinJobs * sizeof(LinJob)) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void**>(&h->lin_tab_bwd_dev), us_decoder::kLinJobs * sizeof(LinJob)) == hipSuccess &&
                 hipMalloc(reinterpret_cast<void**>(&h->pack_tab_dev), us_decoder::kStageBytes) == hipSuccess;
   for (int i = 0; i < 4 && tab_ok; ++i)
     tab_ok = hipHostMalloc(reinterpret_cast<void**>(&h->copy_tab_host[i]), us_decoder::kStageBytes) == hipSuccess;
@@ -1254,6 +1288,8 @@ int us_decoder_destroy(us_handle h) {
   if (h->zeros) (void)hipFree(h->zeros);
   if (h->copy_tab_dev) (void)hipFree(h->copy_tab_dev);
   if (h->grad_tab_dev) (void)hipFree(h->grad_tab_dev);
+  if (h->lin_tab_dev) (void)hipFree(h->lin_tab_dev);
+  if (h->lin_tab_bwd_dev) (void)hipFree(h->lin_tab_bwd_dev);
   if (h->pack_tab_dev) (void)hipFree(h->pack_tab_dev);
   if (h->range_flag) (void)hipFree(h->range_flag);
   if (h->range_host) (void)hipHostFree(h->range_host);

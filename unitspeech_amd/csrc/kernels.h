@@ -353,6 +353,18 @@ hipError_t launch_add2(const float* a, int a_ld, const float* b, int b_ld, float
 hipError_t launch_linear_bwd(const float* gy, int gy_ld, const float* W, const float* x, int x_ld, int rows, int in_dim, int out_dim,
                              bool mish_in, float* gW, float* gb, float* gx, int gx_ld, hipStream_t s);
 hipError_t launch_mul_mish_grad(float* g, int g_ld, const float* x, int x_ld, int rows, int n, hipStream_t s);
+// The same layers as ONE launch per direction for a set of linear layers that share their input (the 22 time projections of the ResnetBlocks,
+// unitspeech.py:61,72): job j owns the output columns [o0, o0 + cout) of the concatenation.  Forward: out_j[r][o] = bias_j[o] + W_j[o] . f(in[r]);
+// backward: gW_j / gb_j accumulated from gy_j (ld cout), gx[r][k] += sum_j sum_o gy_j[r][o] W_j[o][k].
+struct LinJob {
+  const float* W; const float* bias; float* out;       // forward ([cout][in_dim], [cout], [rows][out_ld])
+  const float* gy; float* gW; float* gb;               // backward ([rows][cout], [cout][in_dim], [cout])
+  int out_ld, o0, cout, pad;
+};
+hipError_t launch_linear_multi(const LinJob* jobs_dev, int njobs, int total_out, const float* in, int in_ld, int rows, int in_dim, bool mish_in,
+                               hipStream_t s);
+hipError_t launch_linear_bwd_multi(const LinJob* jobs_dev, int njobs, int total_out, const float* x, int x_ld, int rows, int in_dim,
+                                   bool mish_in, float* gx, int gx_ld, hipStream_t s);
 
 }  // namespace us
 

@@ -417,6 +417,38 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ i
   if (lane == 0) out[(long long)r * out_ld + o] = acc + (bias ? bias[o] : 0.f);
 }
 
+// several layers on one input: one wave per output element of the concatenated outputs (LinJob, kernels.h); per element the arithmetic of
+// linear_kernel, so the result does not depend on which of the two computed it
+__global__ __launch_bounds__(256) void linear_multi_kernel(const LinJob* __restrict__ jobs, int njobs, int total_out, const float* __restrict__ in,
+                                                           int in_ld, int in_dim, int mish_in) {
+  const int r = blockIdx.y;
+  const int og = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (og >= total_out) return;
+  int j = 0;
+  while (j + 1 < njobs && og >= jobs[j + 1].o0) ++j;
+  const LinJob jb = jobs[j];
+  const int o = og - jb.o0;
+  const float* x = in + (long long)r * in_ld;
+  const float* w = jb.W + (long long)o * in_dim;
+  float acc = 0.f;
+  for (int i = lane; i < in_dim; i += 64) {
+    float v = x[i];
+    if (mish_in) v = mish_f(v);
+    acc = fmaf(w[i], v, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) jb.out[(long long)r * jb.out_ld + o] = acc + (jb.bias ? jb.bias[o] : 0.f);
+}
+
+hipError_t launch_linear_multi(const LinJob* jobs_dev, int njobs, int total_out, const float* in, int in_ld, int rows, int in_dim, bool mish_in,
+                               hipStream_t s) {
+  if (rows <= 0 || njobs <= 0 || total_out <= 0) return hipSuccess;
+  hipLaunchKernelGGL(linear_multi_kernel, dim3((total_out + 3) / 4, rows), dim3(256), 0, s, jobs_dev, njobs, total_out, in, in_ld, in_dim,
+                     mish_in ? 1 : 0);
+  return hipGetLastError();
+}
+
 hipError_t launch_linear(const float* in, int in_ld, const float* W, const float* bias, float* out, int out_ld, int rows,
                          int in_dim, int out_dim, bool mish_in, hipStream_t s) {
   if (rows <= 0) return hipSuccess;

@@ -1092,6 +1092,73 @@ __global__ void mul_mish_grad_kernel(float* __restrict__ g, int g_ld, const floa
   g[(long long)r * g_ld + k] *= mish_grad(x[(long long)r * x_ld + k]);
 }
 
+// LinJob sets (kernels.h): the weight / bias gradients of all jobs in one launch, the input gradient in another
+__global__ void linear_bwd_w_multi_kernel(const LinJob* __restrict__ jobs, int njobs, int total_out, const float* __restrict__ x, int x_ld, int rows,
+                                          int in_dim, int mish_in) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= (long long)total_out * in_dim) return;
+  const int og = (int)(i / in_dim), k = (int)(i % in_dim);
+  int j = 0;
+  while (j + 1 < njobs && og >= jobs[j + 1].o0) ++j;
+  const LinJob jb = jobs[j];
+  const int o = og - jb.o0;
+  float acc = 0.f, accb = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    float xv = x[(long long)r * x_ld + k];
+    if (mish_in) xv = mish_fwd(xv);
+    const float g = jb.gy[(long long)r * jb.cout + o];
+    acc += g * xv;
+    accb += g;
+  }
+  atomicAdd(&jb.gW[(long long)o * in_dim + k], acc);
+  if (k == 0 && jb.gb) atomicAdd(&jb.gb[o], accb);
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_x_multi_kernel(const LinJob* __restrict__ jobs, int njobs, int total_out, int in_dim,
+                                                                 int per_slice, float* __restrict__ gx, int gx_ld) {
+  const int r = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= in_dim) return;
+  const int o0 = blockIdx.z * per_slice;
+  int o1 = o0 + per_slice;
+  if (o1 > total_out) o1 = total_out;
+  int j = 0;
+  while (j + 1 < njobs && o0 >= jobs[j + 1].o0) ++j;
+  float a0 = 0.f, a1 = 0.f;
+  for (int og = o0; og < o1;) {
+    while (j + 1 < njobs && og >= jobs[j + 1].o0) ++j;
+    const LinJob jb = jobs[j];
+    int oe = jb.o0 + jb.cout;
+    if (oe > o1) oe = o1;
+    const float* gy = jb.gy + (long long)r * jb.cout - jb.o0;         // indexed by the global column
+    const float* W = jb.W - (long long)jb.o0 * in_dim;
+    int o = og;
+    for (; o + 2 <= oe; o += 2) {
+      a0 = fmaf(gy[o], W[(long long)o * in_dim + k], a0);
+      a1 = fmaf(gy[o + 1], W[(long long)(o + 1) * in_dim + k], a1);
+    }
+    if (o < oe) a0 = fmaf(gy[o], W[(long long)o * in_dim + k], a0);
+    og = oe;
+  }
+  atomicAdd(gx + (long long)r * gx_ld + k, a0 + a1);
+}
+
+hipError_t launch_linear_bwd_multi(const LinJob* jobs_dev, int njobs, int total_out, const float* x, int x_ld, int rows, int in_dim,
+                                   bool mish_in, float* gx, int gx_ld, hipStream_t s) {
+  if (rows <= 0 || njobs <= 0 || total_out <= 0) return hipSuccess;
+  const long long tot = (long long)total_out * in_dim;
+  hipLaunchKernelGGL(linear_bwd_w_multi_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, jobs_dev, njobs, total_out, x, x_ld, rows,
+                     in_dim, mish_in ? 1 : 0);
+  if (gx) {
+    int nslice = (total_out + 63) / 64;
+    if (nslice > 160) nslice = 160;
+    const int per_slice = (total_out + nslice - 1) / nslice;
+    hipLaunchKernelGGL(linear_bwd_x_multi_kernel, dim3((in_dim + 255) / 256, rows, nslice), dim3(256), 0, s, jobs_dev, njobs, total_out, in_dim,
+                       per_slice, gx, gx_ld);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_mul_mish_grad(float* g, int g_ld, const float* x, int x_ld, int rows, int n, hipStream_t s) {
   hipLaunchKernelGGL(mul_mish_grad_kernel, dim3((rows * n + 255) / 256), dim3(256), 0, s, g, g_ld, x, x_ld, rows, n);
   return hipGetLastError();
