@@ -254,7 +254,21 @@ __global__ __launch_bounds__(256) void finetune_segment_kernel(const float* __re
     float yc = 0.f, cy = 0.f;
     if (live) {
       yc = y[((long long)b * F + f) * Ly + src];
-      for (int l = 0; l < Lu; ++l) cy = fmaf(attn[((long long)b * Lu + l) * Ly + src], cond_x[((long long)b * F + f) * Lu + l], cy);
+      // four chains in flight (one was 200 dependent load pairs: 80 us for a 176-frame crop); with a hard alignment -- one 1 per frame,
+      // what generate_path and MAS produce -- every order of the sum gives the same bits
+      const float* ap = attn + (long long)b * Lu * Ly + src;
+      const float* cp = cond_x + ((long long)b * F + f) * Lu;
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+      int l = 0;
+#pragma unroll 2
+      for (; l + 4 <= Lu; l += 4) {
+        c0 = fmaf(ap[(long long)l * Ly], cp[l], c0);
+        c1 = fmaf(ap[(long long)(l + 1) * Ly], cp[l + 1], c1);
+        c2 = fmaf(ap[(long long)(l + 2) * Ly], cp[l + 2], c2);
+        c3 = fmaf(ap[(long long)(l + 3) * Ly], cp[l + 3], c3);
+      }
+      for (; l < Lu; ++l) c0 = fmaf(ap[(long long)l * Ly], cp[l], c0);
+      cy = (c0 + c1) + (c2 + c3);
     }
     y_cut[i] = yc;
     cond_y[i] = cy;
