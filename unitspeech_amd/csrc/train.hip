@@ -410,7 +410,14 @@ __global__ __launch_bounds__(256) void wgrad_amax_kernel(const float* __restrict
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __float_as_uint(mx));
+  // one atomic per block on the ONE result word (they serialise in the L2: 4,096 of them per launch were tens of microseconds)
+  __shared__ float s_mx[4];
+  if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    if (mx > 0.f) atomicMax(out, __float_as_uint(mx));
+  }
 }
 
 hipError_t launch_wgrad_amax(const float* g, int ld, long long rows, int C, float* out, hipStream_t s) {
@@ -418,7 +425,7 @@ hipError_t launch_wgrad_amax(const float* g, int ld, long long rows, int C, floa
   const long long total = rows * (C / 4);
   long long blocks = (total + 256 * 8 - 1) / (256 * 8);
   if (blocks < 1) blocks = 1;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(wgrad_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, ld, rows, C, reinterpret_cast<unsigned*>(out));
   return hipGetLastError();
 }
@@ -711,10 +718,16 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   } else {
     if (a.gbias)
       for (int k = threadIdx.x; k < C; k += 256) atomicAdd(&a.gbias[k], s_ch[0][k]);
-    if (a.gy_amax) {               // as wgrad_amax_kernel: non-negative floats order like their bit patterns
+    if (a.gy_amax) {               // as wgrad_amax_kernel: non-negative floats order like their bit patterns; one atomic per block
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) gy_max = fmaxf(gy_max, __shfl_xor(gy_max, off));
-      if ((threadIdx.x & 63) == 0 && gy_max > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.gy_amax), __float_as_uint(gy_max));
+      __syncthreads();             // (s_mean is dead: every thread is past its loop)
+      if ((threadIdx.x & 63) == 0) s_mean[threadIdx.x >> 6] = gy_max;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        gy_max = fmaxf(fmaxf(s_mean[0], s_mean[1]), fmaxf(s_mean[2], s_mean[3]));
+        if (gy_max > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.gy_amax), __float_as_uint(gy_max));
+      }
     }
   }
 }
