@@ -869,7 +869,10 @@ __global__ __launch_bounds__(256) void attn_bwd_wout_kernel(const float* __restr
     atomicAdd(&gwout[i], acc * g[0]);
   }
   dot = wsum(dot);
-  if ((threadIdx.x & 63) == 0) atomicAdd(gg, dot);
+  __shared__ float s_dot[4];                  // one atomic per block on the single gain-gradient word
+  if ((threadIdx.x & 63) == 0) s_dot[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(gg, (s_dot[0] + s_dot[1]) + (s_dot[2] + s_dot[3]));
 }
 
 hipError_t launch_attn_bwd_wout(const float* M1, const float* ctx, const float* wout, const float* g, int B, int C, float* gwout,
@@ -948,8 +951,13 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
   }
   if (fixed_c && c_mine >= 0) atomicAdd(&s_w[c_mine], wacc);
   gbacc = wsum(gbacc);
-  if ((threadIdx.x & 63) == 0 && gbacc != 0.f) atomicAdd(gb0, gbacc);
+  __shared__ float s_gb[4];                   // one atomic per block on the single bias-gradient word
+  if ((threadIdx.x & 63) == 0) s_gb[threadIdx.x >> 6] = gbacc;
   __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (s_gb[0] + s_gb[1]) + (s_gb[2] + s_gb[3]);
+    if (t != 0.f) atomicAdd(gb0, t);
+  }
   for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&gw[i], s_w[i]);
 }
 
