@@ -556,8 +556,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
   const int rl = threadIdx.x >> 6;
   __shared__ float red[4][64];
   float acc = 0.f;
-  if (c < C)
-    for (long long r = blockIdx.x * 4LL + rl; r < rows; r += (long long)gridDim.x * 4) acc += g[r * ld + c];
+  if (c < C) {
+    // four loads in flight per thread (one dependent load per iteration made these reductions 16-20 us at one crop)
+    const long long st = (long long)gridDim.x * 4;
+    long long r = blockIdx.x * 4LL + rl;
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (; r + 3 * st < rows; r += 4 * st) {
+      acc += g[r * ld + c];
+      a1 += g[(r + st) * ld + c];
+      a2 += g[(r + 2 * st) * ld + c];
+      a3 += g[(r + 3 * st) * ld + c];
+    }
+    for (; r < rows; r += st) acc += g[r * ld + c];
+    acc = (acc + a1) + (a2 + a3);
+  }
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rl == 0 && c < C) {
@@ -1208,8 +1220,20 @@ __global__ __launch_bounds__(256) void rowsum_per_item_kernel(const float* __res
   const int rl = threadIdx.x >> 6;
   __shared__ float red[4][64];
   float acc = 0.f;
-  if (c < C)
-    for (long long r = blockIdx.x * 4LL + rl; r < n; r += (long long)gridDim.x * 4) acc += g[((long long)b * n + r) * ld + c];
+  if (c < C) {
+    const float* gb = g + (long long)b * n * ld + c;
+    const long long st = (long long)gridDim.x * 4;
+    long long r = blockIdx.x * 4LL + rl;
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (; r + 3 * st < n; r += 4 * st) {
+      acc += gb[r * ld];
+      a1 += gb[(r + st) * ld];
+      a2 += gb[(r + 2 * st) * ld];
+      a3 += gb[(r + 3 * st) * ld];
+    }
+    for (; r < n; r += st) acc += gb[r * ld];
+    acc = (acc + a1) + (a2 + a3);
+  }
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rl == 0 && c < C) atomicAdd(&out[(long long)b * C + c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
