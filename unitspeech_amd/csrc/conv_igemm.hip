@@ -883,7 +883,16 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
     const int m = (int)(i / C4);
     const float* p = a.splitk_ws + ((long long)b * Ms + m) * a.Cout + n;
     f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    for (int k = 1; k < a.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p + k * slice);
+    // (eight slices' loads in flight; the sum keeps its slice order)
+    int k = 1;
+    for (; k + 8 <= a.ksplit; k += 8) {
+      f32x4 u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const f32x4*>(p + (k + j) * slice);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += u[j];
+    }
+    for (; k < a.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p + k * slice);
     if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
     if (a.stats) {
       if (tn >= 0 && tn != n) {          // (only when the grid stride is not a multiple of Cout/4: flush and restart)
