@@ -509,7 +509,31 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// Conv2d layout without the four 64-bit divisions per element of the generic kernel: block row = output channel, thread = input channel,
+// the taps in a register loop (reads coalesced over ci per tap, 4 * taps contiguous bytes written per thread)
+template <int TAPS>
+__global__ __launch_bounds__(256) void unpack_wgrad_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin,
+                                                                const float* __restrict__ scale) {
+  const float k = scale ? scale[0] : 1.f;
+  const int co = blockIdx.y;
+  const int ci = blockIdx.x * 256 + threadIdx.x;
+  if (ci >= Cin) return;
+  float v[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) v[t] = src[((long long)t * Cout + co) * Cin + ci];
+  float* d = dst + ((long long)co * Cin + ci) * TAPS;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) d[t] = v[t] * k;
+}
+
 hipError_t launch_unpack_wgrad(const float* src, float* dst, int Cout, int Cin, int taps, bool oihw, hipStream_t s, const float* scale) {
+  static const bool generic = [] { const char* p = getenv("US_UNPACK_GENERIC"); return p && atoi(p) != 0; }();
+  if (!generic && oihw && (taps == 9 || taps == 1) && Cout <= 65535) {
+    const dim3 grid((Cin + 255) / 256, Cout);
+    if (taps == 9) hipLaunchKernelGGL(unpack_wgrad_oihw_kernel<9>, grid, dim3(256), 0, s, src, dst, Cout, Cin, scale);
+    else hipLaunchKernelGGL(unpack_wgrad_oihw_kernel<1>, grid, dim3(256), 0, s, src, dst, Cout, Cin, scale);
+    return hipGetLastError();
+  }
   long long total = (long long)taps * Cout * Cin;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
