@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="diffusion steps timed on the host CPU")
     ap.add_argument("--profile-steps", type=int, default=2, help="untimed decodes after the timed region whose conv launches are event-sampled")
+    ap.add_argument("--no-anchor", action="store_true",
+                    help="skip the untimed anchor legs after the timed region: one decode on an exact-fp32 (v_mfma_f32_32x32x2_f32) handle with "
+                         "the same inputs and noise, and the replay of the reference's 50-step T=1024 golden")
     a = ap.parse_args(argv)
     cb, cg = CONFIGS[a.config] if a.config else (1, 1)
     if a.batch is None:
@@ -151,6 +154,42 @@ class HipWorkload:
     def sync(self):
         torch.cuda.synchronize()
 
+    def exact_anchor(self):
+        """The headline runs on f16x3 GEMMs (fp32-accurate split-operand products on the fp16 matrix cores).  Anchor it, in the same
+        record, to the reference's own arithmetic: the same decode (same z, same Philox noise) on a US_CREATE_EXACT_FP32 handle -- every
+        GEMM on v_mfma_f32_32x32x2_f32 -- timed once after a warm-up, and the mel-L1 distance of the two outputs."""
+        a = self.a
+        default = self.step()
+        self.sync()
+        self.model.exact = True
+        try:
+            self.step()                           # creates the exact engine, packs its weights
+            self.sync()
+            t0 = time.perf_counter()
+            ex = self.step()
+            self.sync()
+            dt = time.perf_counter() - t0
+        finally:
+            self.model.exact = False
+        return {"value": a.batch * a.frames / dt, "unit": "mel-frames/s", "ms_per_step": 1e3 * dt,
+                "mel_l1_vs_default": float((ex - default).abs().mean()), "mean_abs_out": float(ex.abs().mean()),
+                "engine": "US_CREATE_EXACT_FP32: every GEMM on v_mfma_f32_32x32x2_f32 (the arithmetic of the fp32 reference), one decode"}
+
+    def golden_anchor(self, cfg):
+        """tests/golden/loop_full_N50_T1024.npz: the REFERENCE's own 50-step decode at 80x1024 (fp32 and fp64 columns; tools/make_goldens_r2.py)
+        replayed on this engine with the golden's explicit noise: mel-L1 against both columns (north-star tolerance 1e-3)."""
+        path = os.path.join(ROOT, "tests", "golden", "loop_full_N50_T1024.npz")
+        if not os.path.exists(path) or cfg != DecoderConfig():
+            return None
+        g = np.load(path)
+        inp = {k: torch.from_numpy(v).to(self.device) for k, v in
+               synthetic_inputs(cfg, 1, 1024, seed=int(g["seed"]), n_steps=50, lengths=[int(g["lengths"][0])]).items()}
+        out = self.model(inp["z"], inp["mask"], inp["cond"], inp["spk_emb"], 50, 1.0, 1.0, noise=inp["noise"]).double().cpu()
+        ref32, ref64 = torch.from_numpy(g["out"]).double(), torch.from_numpy(g["out_fp64"]).double()
+        return {"vs_reference_fp32": float((out - ref32).abs().mean()), "vs_reference_fp64": float((out - ref64).abs().mean()),
+                "reference_fp32_vs_fp64": float((ref32 - ref64).abs().mean()), "mean_abs_out": float(ref32.abs().mean()),
+                "tolerance": 1e-3, "golden": "tests/golden/loop_full_N50_T1024.npz"}
+
     def profile_begin(self):
         self.eng = self.model._sync(self.device)      # creates the handle / pushes the weights when no warm-up step has run yet
         self.eng.lib.us_profile_enable(self.eng.handle, 1)
@@ -170,19 +209,33 @@ class HipWorkload:
                 "f16_ms": f_ms.value, "f16_flops": f_fl.value, "f16_launches": int(f_n.value)}
 
 
+# the sources whose kernels the HBM-side counters of profiles/*_pmc_summary.json were collected on (inference path)
+TRAFFIC_SOURCES = ("conv_igemm.hip", "wino.hip", "ops.hip", "attn.hip", "decoder.hip", "kernels.h", "pack_f16.h")
+
+
 def pmc_traffic():
-    """HBM-side bytes from the committed counter summary (separate rocprofv3 --pmc passes, tools/pmc_collect.sh + pmc_summary.py), with
-    the commit it was measured at: constants of that commit, not of the run that prints them.  Returns (bytes per conv launch, bytes of
-    ALL kernels per score-network evaluation at B' = 3, 80x1024, source)."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_traffic.json"):
+    """HBM-side bytes from the committed counter summary (separate rocprofv3 --pmc passes, tools/pmc_collect.sh + pmc_summary.py): figures
+    of the tree they were collected on, not of the run that prints them.  So the summary carries a fingerprint of the inference kernels'
+    sources (`source_sha256`, unitspeech_amd/_build.py), and a summary whose fingerprint differs from the tree bench.py runs from is
+    REFUSED: `traffic` is null and `"stale": true` (the refused figures stay visible under `stale_values`).  (The GPU box has no .git, so
+    the check is on file contents, not on `git diff <commit> HEAD`.)  Returns (bytes per conv launch, bytes of ALL kernels per
+    score-network evaluation at B' = 3, 80x1024, source)."""
+    from unitspeech_amd._build import source_fingerprint
+    now = source_fingerprint(TRAFFIC_SOURCES)
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
                 d = json.load(open(path))
-                return (d.get("hbm_bytes_per_launch"), d.get("all_kernels_hbm_side_bytes_per_evaluation"),
-                        {"file": "profiles/" + name, "commit": d.get("commit")})
             except Exception:
-                pass
+                continue
+            src = {"file": "profiles/" + name, "commit": d.get("commit"), "source_sha256": d.get("source_sha256"), "tree_sha256": now}
+            per_launch, per_eval = d.get("hbm_bytes_per_launch"), d.get("all_kernels_hbm_side_bytes_per_evaluation")
+            if d.get("source_sha256") != now:
+                src.update({"stale": True, "stale_values": {"hbm_bytes_per_launch": per_launch, "all_kernels_per_eval": per_eval}})
+                return None, None, src
+            src["stale"] = False
+            return per_launch, per_eval, src
     return None, None, None
 
 
@@ -268,6 +321,10 @@ def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, de
         wl.step()
     wl.sync()
     prof = wl.profile_end()
+    anchors = {}
+    if rank == 0 and not a.no_anchor and hasattr(wl, "exact_anchor"):
+        anchors["exact_fp32"] = wl.exact_anchor()
+        anchors["golden_mel_l1"] = wl.golden_anchor(cfg)
 
     res = None
     if rank == 0:
@@ -327,6 +384,11 @@ def run_rank(a, rank, local, world, backend="nccl", workload_cls=HipWorkload, de
                           "batch_per_gpu": B, "frames": T, "diffusion_steps": N, "parallelism": f"utterance-sharded x{world}"},
                "rtf": (elapsed / a.steps) / (B * T * HOP / SR),
                "roofline": roofline}
+        for k, v in anchors.items():
+            if v is not None:
+                res[k] = v
+        if "exact_fp32" in res:
+            res["exact_fp32"]["default_over_exact"] = value / world / res["exact_fp32"]["value"] if res["exact_fp32"]["value"] > 0 else None
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, T, N, a.cpu_baseline_steps)
     if dist is not None and backend == "nccl":

@@ -246,8 +246,10 @@ int us_duration_predictor_forward(us_frontend_handle h, const float* x, const fl
  * x / out: pixel-major [B][H][W][C] (the library's internal activation layout), x already multiplied by the frame mask
  * where the reference masks the operand; mask: full-resolution [B][T]; temb: [B][dim + spk_emb_dim] (ResnetBlock only).
  * Output masking follows the library's producer-side convention (attention / Downsample / Upsample outputs are stored
- * masked): pass an all-ones mask to obtain the reference module's raw output. */
-enum { US_DEBUG_BLOCK = 0, US_DEBUG_RESNET = 1, US_DEBUG_ATTENTION = 2, US_DEBUG_DOWN = 3, US_DEBUG_UP = 4 };
+ * masked): pass an all-ones mask to obtain the reference module's raw output.
+ * US_DEBUG_TEMB (prefix ignored): x = t [B], out [B][2 * dim] = SinusoidalPosEmb(t) | mlp(SinusoidalPosEmb(t))
+ * (unitspeech/unitspeech.py:109-121, 133-134, 165-166). */
+enum { US_DEBUG_BLOCK = 0, US_DEBUG_RESNET = 1, US_DEBUG_ATTENTION = 2, US_DEBUG_DOWN = 3, US_DEBUG_UP = 4, US_DEBUG_TEMB = 5 };
 int us_debug_block(us_handle h, int kind, const char* prefix, int level, const float* x, const float* mask,
                    const float* temb, float* out, int B, int T, void* workspace, size_t workspace_bytes, us_stream stream);
 

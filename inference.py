@@ -41,6 +41,11 @@ def main():
                     help="--synthetic: run the HIP text encoder + duration predictor with seeded weights instead of the closed-form stand-ins")
     ap.add_argument("--reference_root", type=str, default=None, help="checkout of adrianstanea/UnitSpeech (non-synthetic mode)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--noise_key", type=int, default=None,
+                    help="draw z and the per-step noise from NumPy Philox(key) in the reference's order (z, then one tensor per step) instead of "
+                         "torch's device generator: the stream the committed goldens were drawn from (tests/golden/tts_*.npz: 4242)")
+    ap.add_argument("--spk_seed", type=int, default=None,
+                    help="--synthetic: the speaker embedding of unitspeech_amd.synthetic_inputs(seed) instead of the --ID-keyed one")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -68,6 +73,9 @@ def main():
             text_encoder, duration_predictor = fe.text_encoder, fe.duration_predictor
         spk = np.random.Generator(np.random.Philox(key=args.ID & 0xffff)).standard_normal((1, 1, cfg.spk_emb_dim), dtype=np.float32)
         spk_emb = torch.from_numpy(spk / np.linalg.norm(spk)).to(device)
+        if args.spk_seed is not None:
+            from unitspeech_amd import synthetic_inputs
+            spk_emb = torch.from_numpy(synthetic_inputs(cfg, 1, 8, seed=args.spk_seed)["spk_emb"]).to(device)
         mel_min, mel_max = torch.tensor(-11.5, device=device), torch.tensor(2.0, device=device)
         phoneme, phoneme_lengths = text_to_ids(args.text, device)
         vocoder = None
@@ -102,6 +110,16 @@ def main():
         phoneme = torch.LongTensor(seq).unsqueeze(0).to(device)
         phoneme_lengths = torch.LongTensor([phoneme.shape[-1]]).to(device)
 
+    restore = None
+    if args.noise_key is not None:
+        # the reference draws z with randn_like (:441) and then one randn per step (:367); serve both from one NumPy Philox stream
+        gen = np.random.Generator(np.random.Philox(key=args.noise_key))
+        restore = (torch.randn_like, torch.randn)
+
+        def draw(shape):
+            return torch.from_numpy(gen.standard_normal(tuple(int(v) for v in shape), dtype=np.float32)).to(device)
+        torch.randn_like = lambda x, **k: draw(x.shape)
+        torch.randn = lambda *shape, **k: draw(shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape)
     t0 = time.perf_counter()
     with torch.no_grad():
         # the de-normalisation of inference.py:140 happens in the sampler's last pass: `mel` is the vocoder's input as it stands
@@ -112,6 +130,8 @@ def main():
             mel_range=(mel_min, mel_max))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if restore is not None:
+        torch.randn_like, torch.randn = restore
     frames = mel.shape[-1]
     print(f"decoded {frames} mel frames in {dt:.3f} s ({frames / dt:.1f} frames/s, RTF {dt / (frames * 256 / 22050):.3f}), "
           f"{args.diffusion_steps} diffusion steps, finite={bool(torch.isfinite(mel).all())}")

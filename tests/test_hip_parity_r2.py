@@ -222,6 +222,32 @@ def test_building_blocks_vs_reference_modules(golden):
     print(f"\nblocks: attention L1 {e_attn:.2e} on a Rezero branch of mean |.| {branch:.2e}")
 
 
+@pytest.mark.parametrize("tag,cfg", [("tiny", TINY), ("full", FULL)])
+def test_time_embedding_vs_reference_golden(golden, tag, cfg):
+    """`SinusoidalPosEmb` + mlp (unitspeech/unitspeech.py:109-121,133-134,165-166) on its own: `pos_emb_kernel` and the two `linear_kernel`
+    launches of time_embedding() through us_debug_block(US_DEBUG_TEMB), against the reference module's outputs at t = 1e-5 ... 0.995
+    (tests/golden/temb_*.npz; arguments of sin / cos up to 995: the range reduction is what this pins)."""
+    g = G(golden(f"temb_{tag}"))
+    model = make_model(cfg)
+    eng = model._sync(torch.device(DEV))
+    lib = eng.lib
+    t = g["t"].to(DEV).contiguous()
+    B, T, dim = t.shape[0], 8, cfg.dim
+    out = torch.empty(B, 2 * dim, device=DEV)
+    ws = torch.empty(int(lib.us_workspace_bytes(eng.handle, B, T)), dtype=torch.uint8, device=DEV)
+    mask = torch.ones(B, T, device=DEV)
+    rc = lib.us_debug_block(eng.handle, 5, b"", 0, C.c_void_p(t.data_ptr()), C.c_void_p(mask.data_ptr()), None, C.c_void_p(out.data_ptr()), B, T,
+                            C.c_void_p(ws.data_ptr()), ws.numel(), None)
+    _lib.check(rc, eng.handle, "us_debug_block(US_DEBUG_TEMB)")
+    torch.cuda.synchronize()
+    pe, mlp = out[:, :dim].cpu(), out[:, dim:].cpu()
+    e_pe, e_mlp = (pe - g["posemb"]).abs().max().item(), (mlp - g["mlp"]).abs().max().item()
+    print(f"\n[{tag}] time embedding: max |posemb - reference| {e_pe:.2e}, max |mlp - reference| {e_mlp:.2e} (mean |mlp| {g['mlp'].abs().mean():.3f})")
+    # sin / cos of arguments up to 995 in fp32: one ulp of the ARGUMENT is 6e-5, the reference (libm sinf of the fp32 product) and a device
+    # sinf of the same product agree to a few 1e-7
+    assert e_pe <= 2e-6 and e_mlp <= 2e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the reference's own execute_text_to_speech (same seeded front-end stand-ins) + fused de-normalisation
 # ---------------------------------------------------------------------------------------------------------------

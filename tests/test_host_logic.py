@@ -91,12 +91,19 @@ def test_f16x3_split_gemm_is_at_fp32_accuracy():
 
 # ---- round 3: the range fall-back of the mirror and the bench's self-description, without a GPU -------------------------------------
 class _FakeEngine:
-    def __init__(self, exact, status=0):
+    def __init__(self, exact, status=0, stale=0):
         self.exact, self._status, self.status_reads = exact, status, 0
+        self.stale, self.clears = stale, 0          # stale: an event an earlier TRAINING call left standing in the device word
+
+    def range_clear(self):
+        self.clears += 1
+        self.stale = 0
 
     def range_status(self, reset=True):
         self.status_reads += 1
-        st, self._status = self._status, 0 if reset else self._status
+        st = self._status | self.stale
+        if reset:
+            self._status = self.stale = 0
         return st
 
 
@@ -114,6 +121,12 @@ def test_run_checked_repeats_a_flagged_inference_call_on_the_exact_engine(monkey
 
     fast, exact = _FakeEngine(False, 0), _FakeEngine(True)
     assert US._run_checked(fast, run, lambda: exact, True, "t") == "fast" and runs == [fast] and fast.status_reads == 1
+    runs.clear()
+    # an event left by the last training iteration must not send an in-range inference call to the exact engine
+    fast = _FakeEngine(False, 0, stale=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert US._run_checked(fast, run, lambda: exact, True, "t") == "fast" and runs == [fast] and fast.clears == 1
     runs.clear()
     fast = _FakeEngine(False, 1)
     with pytest.warns(RuntimeWarning, match="exact-fp32"):

@@ -50,6 +50,16 @@ except Exception:
     res["commit"] = os.environ.get("US_COMMIT")
 
 
+try:      # fingerprint of the inference kernels' sources: bench.py refuses this summary's traffic figures on any other tree
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as _bench
+    from unitspeech_amd._build import source_fingerprint
+    res["source_sha256"] = source_fingerprint(_bench.TRAFFIC_SOURCES)
+except Exception as e:      # noqa: BLE001
+    res["source_sha256"] = None
+    print("no source fingerprint:", e)
+
+
 def derive(c, n):
     o = {"dispatches": n}
     o.update({k: v for k, v in c.items() if not k.startswith("_")})

@@ -15,6 +15,18 @@ HEADERS = ["kernels.h", "pack_f16.h", "train_host.inc", "train_abi.inc", os.path
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def source_fingerprint(names) -> str:
+    """sha256 over the named files of csrc/ (name and contents, in the given order): what ties a committed measurement to the kernels it
+    was taken on without needing .git (bench.py: pmc_traffic; tools/pmc_summary.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        h.update(n.encode() + b"\0")
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(cc):

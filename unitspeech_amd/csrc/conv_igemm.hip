@@ -811,7 +811,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
           const int oy = oy0 + yy * a.ostep;
           if (edge && (oy >= a.Hout || ox >= a.Wout)) continue;
           const long long pix = dense ? (long long)m : (long long)oy * a.Wout + ox;
-          v = (v + b4) * alpha;
+          v = v + b4;
+          if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + ((long long)b * a.Hout * a.Wout + pix) * a.out2_ld + n) = v;
+          v = v * alpha;
           if (add_b) v += *reinterpret_cast<const f32x4*>(add_b + pix * a.add_ld + n);
           if (om_b) v *= om_b[ox * a.omask_step];
           if (a.out_split) {
@@ -910,6 +912,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
     const int yy = m / a.Ws, xx = m - yy * a.Ws;
     const int ox = a.ox0 + xx * a.ostep;
     const long long pix = dense ? (long long)m : (long long)(a.oy0 + yy * a.ostep) * a.Wout + ox;
+    if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + ((long long)b * a.Hout * a.Wout + pix) * a.out2_ld + n) = v;
     v *= alpha;
     if (add_b) v += *reinterpret_cast<const f32x4*>(add_b + pix * a.add_ld + n);
     if (om_b) v *= om_b[ox * a.omask_step];
@@ -974,6 +977,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     int cg = a.Cout / kGroups;
     if (a.Cout % kGroups != 0 || (cg & (cg - 1)) != 0) return hipErrorInvalidValue;
   }
+  if (a.out2 && (a.out2_ld % 4 != 0 || a.wino_out || a.out_split || a.attn_part_ctx)) return hipErrorInvalidValue;
   if (g_f16_tm < 0) {
     const char* e = getenv("US_F16_TM");
     g_f16_tm = e ? atoi(e) : 0;

@@ -153,6 +153,7 @@ struct us_decoder {
   CopyEnt* copy_tab_dev = nullptr;
   CopyEnt* copy_tab_host[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring
   static constexpr int kCaptureTabs = 32;
+  size_t copy_tab_capture_bytes[kCaptureTabs] = {};
   CopyEnt* copy_tab_capture[kCaptureTabs] = {};    // write-once staging for uploads recorded into a HIP graph (no allocation is legal
   int copy_tab_capture_used = 0;                    // while a stream captures): one per captured weight sync
   hipEvent_t copy_tab_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -599,9 +600,10 @@ hipError_t conv3x3(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int l
 // in_split: `in` holds the two-plane fp16 form (its producer stored it with out_split; f16x3 convolutions only); out_split: store it so
 hipError_t conv1x1(EvalCtx& e, const ConvW& w, const float* in, int in_ld, int level, bool mask_out, float* out, int out_ld,
                    const float* add, int add_ld, const float* alpha, const float* wt_override, long long wt_bstride,
-                   const float* bias_override, bool in_split = false, bool out_split = false) {
+                   const float* bias_override, bool in_split = false, bool out_split = false, float* out2 = nullptr, int out2_ld = 0) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   ConvArgs a = base_args(e, w, in, in_ld, H, W, out, out_ld, H, W);
+  a.out2 = out2; a.out2_ld = out2_ld;
   if (in_split) {
     if (a.f16 != 2) return hipErrorInvalidValue;
     a.f16 = 1;
@@ -1095,9 +1097,17 @@ int upload_bytes(us_decoder* h, const void* ents, size_t nbytes, void* dev, hipS
   CopyEnt* host = h->copy_tab_host[slot];
   if (cap != hipStreamCaptureStatusNone) {
     // a captured upload reads its host source at every replay: give it storage of its own that is never rewritten
-    if (h->copy_tab_capture_used >= us_decoder::kCaptureTabs)
-      return h->fail(US_EINVAL, "more than %d weight syncs / backward passes recorded into HIP graphs with this handle", us_decoder::kCaptureTabs);
-    host = h->copy_tab_capture[h->copy_tab_capture_used++];
+    // ... and a table with these very bytes recorded by an earlier capture (the job tables of a FineTuneGraph hold the same pointers every
+    // time one is built on this handle) serves this one too, so that per-speaker loops that re-capture do not run out of entries
+    host = nullptr;
+    for (int i = 0; i < h->copy_tab_capture_used && !host; ++i)
+      if (h->copy_tab_capture_bytes[i] == n && memcmp(h->copy_tab_capture[i], ents, n) == 0) host = h->copy_tab_capture[i];
+    if (!host) {
+      if (h->copy_tab_capture_used >= us_decoder::kCaptureTabs)
+        return h->fail(US_EINVAL, "more than %d distinct weight syncs / backward passes recorded into HIP graphs with this handle", us_decoder::kCaptureTabs);
+      h->copy_tab_capture_bytes[h->copy_tab_capture_used] = n;
+      host = h->copy_tab_capture[h->copy_tab_capture_used++];
+    }
   } else if (h->copy_tab_ev[slot]) {
     (void)hipEventSynchronize(h->copy_tab_ev[slot]);      // the upload that last used this staging slot has completed
   }
@@ -1685,6 +1695,17 @@ int us_debug_block(us_handle h, int kind, const char* prefix, int level, const f
   for (auto& d : h->downs) { rs.push_back(&d.r1); rs.push_back(&d.r2); as.push_back(&d.a); }
   rs.push_back(&h->mid1); rs.push_back(&h->mid2); as.push_back(&h->mid_attn);
   for (auto& u : h->ups) { rs.push_back(&u.r1); rs.push_back(&u.r2); as.push_back(&u.a); }
+  if (kind == US_DEBUG_TEMB) {
+    // x = t [B]; out [B][2 * dim] = SinusoidalPosEmb(t) | mlp(SinusoidalPosEmb(t))  (unitspeech.py:109-121,133-134,165-166), by the launches
+    // time_embedding() makes
+    const int dim = h->cfg.dim;
+    US_HIP(h, launch_pos_emb(x, b.posemb, B, dim, h->cfg.pe_scale, s));
+    US_HIP(h, launch_linear(b.posemb, dim, h->mlp0_w->buf.p, h->mlp0_b->buf.p, b.mlp_h, 4 * dim, B, dim, 4 * dim, false, s));
+    US_HIP(h, launch_linear(b.mlp_h, 4 * dim, h->mlp2_w->buf.p, h->mlp2_b->buf.p, b.temb, dim + h->cfg.spk_emb_dim, B, 4 * dim, dim, true, s));
+    US_HIP(h, launch_copy_rows(b.posemb, dim, B, out, 2 * dim, B, dim, s));
+    US_HIP(h, launch_copy_rows(b.temb, dim + h->cfg.spk_emb_dim, B, out + dim, 2 * dim, B, dim, s));
+    return US_OK;
+  }
   if (kind == US_DEBUG_BLOCK || kind == US_DEBUG_RESNET) {
     for (const ResnetW* r0 : rs) {
       if (r0->mlp_w->key != p + ".mlp.1.weight") continue;

@@ -122,6 +122,8 @@ struct ConvArgs {
   int attn_q_cols;       // kHidden: column tile 0 is q and is stored; 0: the launch computes k | v only (Cout = 2 * kHidden, nothing stored:
                          // the caller folds W_q into the output projection, launch_attn_wtotal)
   int wt_rows;           // rows per K-chunk of the packed weight when the launch uses only Cout of them (0: Cout)
+  float* out2;           // optional second output, pixel-indexed like out (ld out2_ld): acc + bias BEFORE alpha / add / mask.  Training keeps
+  int out2_ld;           // the Rezero branch's fn(x) this way: the gain's gradient is sum(grad_out * fn(x)) (unitspeech/unitspeech.py:36-43)
 #ifdef US_STAMP
   unsigned long long* stamp_out;   // diagnostic build only: per (workgroup, wave) {cycles at the vmcnt wait, at the barrier, in the body, steps}
 #endif
@@ -343,8 +345,21 @@ hipError_t launch_attn_bwd_wout(const float* M1, const float* ctx, const float* 
                                 float* gg, hipStream_t s);
 hipError_t launch_attn_bwd_bias(const float* colsumG, const float* bout, const float* g, int C, float* gbout, float* gg, hipStream_t s);
 hipError_t launch_attn_weff_dgrad(const float* ctx, const float* wout, float* dst, int B, int C, int bk, hipStream_t s);
+// gb0_partials: final_bwd_blocks(B, H, W, C) * B fp64 partial sums of the bias gradient, item-major (launch_reduce_finalize adds them up)
+int final_bwd_blocks(int B, int H, int W, int C);
 hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float* w, const float* mask, int mask_ld, int mask_bmod,
-                            float* gh, float* gw, float* gb0, int B, int H, int W, int C, hipStream_t s);
+                            float* gh, float* gw, double* gb0_partials, int B, int H, int W, int C, hipStream_t s);
+// Fixed-order fp64 reductions to one scalar (train.hip): partials[i] = the i-th block's share of sum_{r, c} a[r][c] * b[r][c], i <
+// dot_partial_blocks(rows, C) <= kRedBlocks; launch_reduce_finalize: dst[j][0] += scale[j][0] * (sum of job j's partials in index order)
+constexpr int kRedBlocks = 256;
+int dot_partial_blocks(long long rows, int C);
+hipError_t launch_dot_partial(const float* a, int a_ld, const float* b, int b_ld, long long rows, int C, double* partials, hipStream_t s);
+struct RedJobs {
+  static constexpr int kMax = 12;
+  const double* p[kMax]; int n[kMax]; float* dst[kMax]; const float* scale[kMax];     // scale: optional device scalar
+  int count;
+};
+hipError_t launch_reduce_finalize(const RedJobs& jobs, hipStream_t s);
 hipError_t launch_first_conv_wgrad(const float* in2, const float* gy, const float* gr, int Bp, int F, int T, int C, float* gw3,
                                    float* gw1, hipStream_t s);
 hipError_t launch_add2(const float* a, int a_ld, const float* b, int b_ld, float* out, int out_ld, long long rows, int C, hipStream_t s);

@@ -896,14 +896,19 @@ __global__ __launch_bounds__(256) void attn_bwd_wout_kernel(const float* __restr
       const float* m1 = M1 + ((long long)b * C + c) * kHidden + h * kDimHead;
       const float* cx = ctx + ((long long)b * kHeads + h) * kDimHead * kDimHead;
       float weff = 0.f;                       // weff_nat[b][c][h*32 + e'] with e' := e playing the role of d
-      for (int d = 0; d < kDimHead; ++d) {
-        acc += m1[d] * cx[d * kDimHead + e];
-        weff += wout[(long long)c * kHidden + h * kDimHead + d] * cx[e * kDimHead + d];
+      if (gg) {
+        for (int d = 0; d < kDimHead; ++d) {
+          acc += m1[d] * cx[d * kDimHead + e];
+          weff += wout[(long long)c * kHidden + h * kDimHead + d] * cx[e * kDimHead + d];
+        }
+      } else {
+        for (int d = 0; d < kDimHead; ++d) acc += m1[d] * cx[d * kDimHead + e];
       }
       dot += weff * m1[e];
     }
     atomicAdd(&gwout[i], acc * g[0]);
   }
+  if (!gg) return;         // the gain's gradient comes from launch_dot_partial (fixed-order fp64 sum of grad_out * fn(x)), not from M1
   dot = wsum(dot);
   __shared__ float s_dot[4];                  // one atomic per block on the single gain-gradient word
   if ((threadIdx.x & 63) == 0) s_dot[threadIdx.x >> 6] = dot;
@@ -925,8 +930,76 @@ __global__ void attn_bwd_bias_kernel(const float* __restrict__ colsumG, const fl
     dot += bout[c] * colsumG[c];
     atomicAdd(&gbout[c], g[0] * colsumG[c]);
   }
+  if (!gg) return;
   dot = wsum(dot);
   if ((threadIdx.x & 63) == 0) atomicAdd(gg, dot);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Deterministic scalar reductions (the Rezero gains' gradients, the final projection's bias gradient).  Rezero(fn)(x) = fn(x) * g
+// (unitspeech/unitspeech.py:36-43), so autograd's g.grad = sum(grad_out * fn(x)): a sum of ~1e6 products that cancel to a few 1e-5.
+// Formed from M1 = G^T q and W_eff (two more roundings in front of the cancellation) and added up by float atomics, the eight gains
+// were 5e-4 ... 1e-3 away from the oracle and moved from run to run; the reference's own fp32 result is within 4e-6 of its fp64 one
+// (tests/golden/grads_full_8x176_fp64.npz).  Here: every block sums its fixed share of the products in fp64 (a float product is exact in
+// a double), writes ONE partial, and reduce_finalize_kernel adds the partials in index order.  No atomics, no dependence on arrival order.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wsum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ void block_partial_store(double v, double* dst) {      // 256 threads; every thread calls
+  __shared__ double s_p[4];
+  v = wsum_d(v);
+  if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *dst = (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]);
+}
+
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld,
+                                                          long long rows, int C, double* __restrict__ partials) {
+  const int C4 = C >> 2;
+  const long long total = rows * C4;
+  double acc = 0.0;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a + r * a_ld + c);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(b + r * b_ld + c);
+    acc += ((double)x[0] * (double)y[0] + (double)x[1] * (double)y[1]) + ((double)x[2] * (double)y[2] + (double)x[3] * (double)y[3]);
+  }
+  block_partial_store(acc, partials + blockIdx.x);
+}
+
+int dot_partial_blocks(long long rows, int C) {
+  long long b = (rows * (C >> 2) + 256 * 8 - 1) / (256 * 8);
+  return (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
+}
+
+hipError_t launch_dot_partial(const float* a, int a_ld, const float* b, int b_ld, long long rows, int C, double* partials, hipStream_t s) {
+  if (C % 4 != 0 || a_ld % 4 != 0 || b_ld % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(dot_partial_blocks(rows, C)), dim3(256), 0, s, a, a_ld, b, b_ld, rows, C, partials);
+  return hipGetLastError();
+}
+
+// dst[j][0] += scale[j] * sum_i p[j][i], i = 0 .. n[j] - 1 in index order (one wave per job: lane l takes i = l, l + 64, ..., then a fixed tree)
+__global__ __launch_bounds__(64) void reduce_finalize_kernel(RedJobs jobs) {
+  const int j = blockIdx.x;
+  const double* p = jobs.p[j];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < jobs.n[j]; i += 64) acc += p[i];
+  acc = wsum_d(acc);
+  if (threadIdx.x == 0) {
+    const double sc = jobs.scale[j] ? (double)jobs.scale[j][0] : 1.0;
+    jobs.dst[j][0] += (float)(acc * sc);
+  }
+}
+
+hipError_t launch_reduce_finalize(const RedJobs& jobs, hipStream_t s) {
+  if (jobs.count <= 0) return hipSuccess;
+  if (jobs.count > RedJobs::kMax) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(reduce_finalize_kernel, dim3(jobs.count), dim3(64), 0, s, jobs);
+  return hipGetLastError();
 }
 
 hipError_t launch_attn_bwd_bias(const float* colsumG, const float* bout, const float* g, int C, float* gbout, float* gg, hipStream_t s) {
@@ -962,14 +1035,14 @@ hipError_t launch_attn_weff_dgrad(const float* ctx, const float* wout, float* ds
 __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ go, const float* __restrict__ h, int ld,
                                                         const float* __restrict__ w, const float* __restrict__ mask, int mask_ld,
                                                         int mask_bmod, int W, long long n, int C, float* __restrict__ gh,
-                                                        float* __restrict__ gw, float* __restrict__ gb0) {
+                                                        float* __restrict__ gw, double* __restrict__ gb0_partials) {
   const int b = blockIdx.y;
   __shared__ float s_w[1024];
   for (int i = threadIdx.x; i < C; i += 256) s_w[i] = 0.f;
   __syncthreads();
   const float* mb = mask + (long long)(b % mask_bmod) * mask_ld;
   const long long total = n * C;
-  float gbacc = 0.f;
+  double gbacc = 0.0;
   // a thread keeps its channel when the grid stride is a multiple of C (every full-size launch): its products are summed in a register
   // and reach the LDS accumulator once
   const bool fixed_c = ((long long)gridDim.x * 256) % C == 0;
@@ -983,31 +1056,31 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     if (fixed_c) { wacc += g * h[idx]; c_mine = c; }
     else atomicAdd(&s_w[c], g * h[idx]);
     gh[idx] = g * w[c];
-    if (c == 0) gbacc += g;
+    if (c == 0) gbacc += (double)g;
   }
   if (fixed_c && c_mine >= 0) atomicAdd(&s_w[c_mine], wacc);
-  gbacc = wsum(gbacc);
-  __shared__ float s_gb[4];                   // one atomic per block on the single bias-gradient word
-  if ((threadIdx.x & 63) == 0) s_gb[threadIdx.x >> 6] = gbacc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = (s_gb[0] + s_gb[1]) + (s_gb[2] + s_gb[3]);
-    if (t != 0.f) atomicAdd(gb0, t);
-  }
+  // the bias gradient sum_p go * m: one fp64 partial per block, added in index order by reduce_finalize_kernel (no atomics: reproducible)
+  block_partial_store(gbacc, gb0_partials + (long long)b * gridDim.x + blockIdx.x);
   for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&gw[i], s_w[i]);
 }
 
-hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float* w, const float* mask, int mask_ld, int mask_bmod,
-                            float* gh, float* gw, float* gb0, int B, int H, int W, int C, hipStream_t s) {
-  if (C > 1024) return hipErrorInvalidValue;
+int final_bwd_blocks(int B, int H, int W, int C) {
   long long n = (long long)H * W;
   int blocks = (int)((n * C + 256 * 16 - 1) / (256 * 16));
   if (blocks < 1) blocks = 1;
   if (blocks > 512) blocks = 512;
-  // every block ends with C atomics on the same C addresses of gw (and one on gb0): cap the launch at 512 blocks over all items, as the
-  // GroupNorm backward (launch_gn_bwd)
+  // every block ends with C atomics on the same C addresses of gw: cap the launch at 512 blocks over all items, as the GroupNorm backward
+  // (launch_gn_bwd)
   if ((long long)blocks * B > 512) blocks = 512 / B < 4 ? 4 : 512 / B;
-  hipLaunchKernelGGL(final_bwd_kernel, dim3(blocks, B), dim3(256), 0, s, go, h, ld, w, mask, mask_ld, mask_bmod, W, n, C, gh, gw, gb0);
+  return blocks;
+}
+
+hipError_t launch_final_bwd(const float* go, const float* h, int ld, const float* w, const float* mask, int mask_ld, int mask_bmod,
+                            float* gh, float* gw, double* gb0_partials, int B, int H, int W, int C, hipStream_t s) {
+  if (C > 1024) return hipErrorInvalidValue;
+  long long n = (long long)H * W;
+  hipLaunchKernelGGL(final_bwd_kernel, dim3(final_bwd_blocks(B, H, W, C), B), dim3(256), 0, s, go, h, ld, w, mask, mask_ld, mask_bmod, W, n, C,
+                     gh, gw, gb0_partials);
   return hipGetLastError();
 }
 

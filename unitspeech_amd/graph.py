@@ -108,9 +108,13 @@ class FineTuneGraph:
         """One `fine_tune` call plus `loss.backward()`: gradients land in `p.grad` (static tensors with backward="graph", fresh views of one
         blob per iteration otherwise), returns the loss (a static tensor)."""
         self._check_alive()
+        # the f16x3 range word: the captured forward cannot poll (no host read inside a capture), so the check lives here, host-side and
+        # outside the replay -- an overflow of iteration i raises RangeError at iteration i + 1, as in the eager loop (_EstimatorFn)
+        self._engine.range_poll()
         self.decoder.fine_tune_segment(cond_x, y, y_lengths, attn, self.segment_size, self.n_feats, out=(self.y, self.mask, self.cond))
         if self.backward == "graph":
             self.graph.replay()
+            self._engine.range_post()             # (the eager backward posts it itself: _EstimatorFn.backward)
             return self.loss
         # forward graph and eager backward on the capture stream (the autograd nodes are bound to it), fenced against the caller's stream on
         # both sides: the crop above and the optimiser step after this call run there

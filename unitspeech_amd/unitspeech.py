@@ -240,6 +240,18 @@ class _Engine:
                        "us_range_status_async")
             self._range_event.record(torch.cuda.current_stream())
 
+    def range_clear(self):
+        """Inference after training on the same engine: training posts the word without resetting it (`range_post`), so an event of the last
+        training iteration would still stand when the next inference call reads its status, and that call would be repeated on an
+        exact-fp32 engine for nothing.  Clears the device word in stream order; a status training has already posted stays in its host copy."""
+        if self.exact or not self.handle or self._range_event is None:
+            return
+        with torch.cuda.device(self.device):
+            if getattr(self, "_range_trash", None) is None:
+                self._range_trash = torch.zeros(1, dtype=torch.int32).pin_memory()
+            _lib.check(self.lib.us_range_status_async(self.handle, C.c_void_p(self._range_trash.data_ptr()), 1, _stream()), self.handle,
+                       "us_range_status_async")
+
     def range_poll(self):
         """Raise RangeError when an earlier training call on this engine reported a tensor beyond the fp16 range."""
         if self.exact or self._range_event is None or not self._range_event.query():
@@ -444,6 +456,8 @@ def _run_checked(eng, run, exact_engine, range_check, what):
     """Inference calls: run on `eng`; when its f16x3 GEMMs met a tensor beyond the fp16 range (the results are then non-finite where it
     mattered, never clamped), repeat the call on the exact-fp32 engine, as the reference's plain fp32 arithmetic would have carried
     the value (unitspeech/unitspeech.py:46-96).  The status read waits for the stream; `range_check=False` skips it."""
+    if not eng.exact and range_check and not torch.cuda.is_current_stream_capturing():
+        eng.range_clear()           # only the status THIS call produces may trigger the repeat (training leaves its events standing)
     out = run(eng)
     if eng.exact or not range_check or torch.cuda.is_current_stream_capturing():
         return out
