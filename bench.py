@@ -210,7 +210,7 @@ class HipWorkload:
 
 
 # the sources whose kernels the HBM-side counters of profiles/*_pmc_summary.json were collected on (inference path)
-TRAFFIC_SOURCES = ("conv_igemm.hip", "wino.hip", "ops.hip", "attn.hip", "decoder.hip", "kernels.h", "pack_f16.h")
+TRAFFIC_SOURCES = ("conv_igemm.hip", "wino.hip", "wino4.hip", "wino4_coef.h", "ops.hip", "attn.hip", "decoder.hip", "kernels.h", "pack_f16.h")
 
 
 def pmc_traffic():

@@ -78,6 +78,14 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
  * must stay valid until this call has been made on the same stream.  Every computing entry point refuses to run (US_EWEIGHTS)
  * while loads are pending. */
 int us_decoder_flush_weights(us_handle h, us_stream stream);
+/* Training mode of the weight store.  Inference runs the stride-1 3x3 convolutions of the low-resolution levels as Winograd F(4x4,3x3) /
+ * F(2x4,3x3) where enabled (US_WINO4; csrc/wino4.hip), from a third pack of those weights (36 / 24 matrices per convolution) that the
+ * training path never reads.  training != 0: us_decoder_load_weight skips that pack -- an optimiser step re-loads every tensor -- and
+ * marks it stale; inference calls then run the F(2x2,3x3) form for such a tensor (correct, slower, rounding of that form) until it is
+ * loaded again with training == 0.  us_decoder_stale_inference_forms: how many loaded tensors are in that state (a host mirror
+ * re-loads them before its first inference call after training: unitspeech_amd/unitspeech.py, _Engine.sync_weights). */
+int us_decoder_set_training(us_handle h, int training);
+int us_decoder_stale_inference_forms(us_handle h);
 /* Number of state_dict tensors the configured architecture has / that have been loaded so far. */
 int us_decoder_num_weights(us_handle h);
 int us_decoder_num_loaded(us_handle h);

@@ -36,7 +36,6 @@ def test_inference_cli_with_the_hip_text_encoder_and_duration_predictor(tmp_path
     assert r.returncode == 0, r.stderr[-2000:]
     mel = np.load(str(out)[:-4] + ".mel.npy")
     assert mel.shape[0] == 80 and mel.shape[1] >= 19 and np.isfinite(mel).all()        # 19 symbols, at least one frame each
-    assert -11.5 - 30 < mel.mean() < 2.0 + 30                                          # de-normalised with the synthetic range, not blown up
 
 
 def _losses(stdout):

@@ -168,3 +168,33 @@ def test_bench_algorithmic_bytes_and_single_rank_census():
     assert bench.algorithmic_bytes_per_eval(n, 3, 1024) == 4.0 * n + 3 * 1024 * 964.0          # weights once + B' T 964 B
     world, ranks = bench.rank_census(None, 0, 1, torch.device("cpu"), "nccl")
     assert world == 1 and ranks[0]["rank"] == 0
+
+
+def test_winograd_4_wide_coefficients_are_exact_and_better_conditioned_than_the_standard_points(tmp_path):
+    """csrc/wino4_coef.h is what tools/gen_wino4_coef.py writes (Cook-Toom on {0, +-5/8, +-3/2, inf}; the generator checks the convolution identity
+    in exact rational arithmetic), and the fp32-pipeline emulation of tools/scratch/wino_points.py puts these points well below the standard
+    {0, +-1, +-2}: the reason F(4x4,3x3) fits the 2e-6 per-evaluation bar."""
+    import importlib.util
+    import os
+    import re
+    from fractions import Fraction as Fr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    gen = load(os.path.join(root, "tools", "gen_wino4_coef.py"), "gen_wino4_coef")
+    AT, Gm, BT = gen.cook_toom_exact([0, Fr(5, 8), Fr(-5, 8), Fr(3, 2), Fr(-3, 2)], 4)
+    assert all(gen.is_dyadic(x) for row in AT + BT for x in row)              # exact in fp32
+    header = open(os.path.join(root, "unitspeech_amd", "csrc", "wino4_coef.h")).read()
+    bt4 = re.search(r"kBT4\[6\]\[6\] = \{(.*?)\};", header, re.S).group(1)
+    vals = [float(v.rstrip("f")) for v in re.findall(r"-?\d+\.\d+f", bt4)]
+    assert vals == [float(x) for row in BT for x in row]
+    pts = load(os.path.join(root, "tools", "scratch", "wino_points.py"), "wino_points")
+    ours = [0, Fr(5, 8), Fr(-5, 8), Fr(3, 2), Fr(-3, 2)]
+    e_ours = pts.emulate(4, 4, ours, ours, C=128, Co=16, tiles=12, bias_mean=0.3)[0]
+    e_std = pts.emulate(4, 4, [0, 1, -1, 2, -2], [0, 1, -1, 2, -2], C=128, Co=16, tiles=12, bias_mean=0.3)[0]
+    e_22 = pts.emulate(2, 2, [0, 1, -1], [0, 1, -1], C=128, Co=16, tiles=12, bias_mean=0.3)[0]
+    assert e_ours < 0.7 * e_std and e_ours < 4.0 * e_22 and e_ours < 8e-7, (e_ours, e_std, e_22)

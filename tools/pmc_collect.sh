@@ -9,7 +9,7 @@ out=gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
 pass() {   # name, counters...
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -o p -- python3 bench.py --steps 1 --warmup 0 --diffusion-steps 4 --no-cpu-baseline > "$out/$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -o p -- python3 bench.py --steps 1 --warmup 0 --diffusion-steps 4 --no-cpu-baseline --no-anchor > "$out/$name.log" 2>&1
   f=$(find "$out/$name" -name '*counter_collection.csv' | head -1)
   if [ -z "$f" ]; then echo "pass $name produced no counters"; tail -3 "$out/$name.log"; return 1; fi
   mv "$f" "$out/$name.csv"; rm -rf "$out/$name"

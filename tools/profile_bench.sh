@@ -6,7 +6,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o t -- python3 bench.py --steps 1 --warmup 0 --profile-steps 1 --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o t -- python3 bench.py --steps 1 --warmup 0 --profile-steps 1 --no-cpu-baseline --no-anchor "$@" > "$out/bench.log" 2>&1
 trace=$(find "$out" -name '*kernel_trace.csv' | head -1)
 stats=$(find "$out" -name '*kernel_stats.csv' | head -1)
 if [ -z "$trace" ] || [ -z "$stats" ]; then echo "no trace produced"; tail -5 "$out/bench.log"; exit 1; fi

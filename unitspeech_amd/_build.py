@@ -9,9 +9,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunitspeech_hip.so")
-SOURCES = ["conv_igemm.hip", "ops.hip", "attn.hip", "wino.hip", "train.hip", "optim.hip", "glue.hip", "frontend.hip", "decoder.hip"]
+SOURCES = ["conv_igemm.hip", "ops.hip", "attn.hip", "wino.hip", "wino4.hip", "train.hip", "optim.hip", "glue.hip", "frontend.hip", "decoder.hip"]
 # every source includes kernels.h; decoder.hip also includes the two .inc files (one stale check for all: a header edit is rare)
-HEADERS = ["kernels.h", "pack_f16.h", "train_host.inc", "train_abi.inc", os.path.join("..", "..", "include", "unitspeech_hip.h")]
+HEADERS = ["kernels.h", "pack_f16.h", "wino4_coef.h", "train_host.inc", "train_abi.inc", os.path.join("..", "..", "include", "unitspeech_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -40,6 +40,8 @@ SIGNATURES = {
     "us_range_status_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "us_decoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     "us_decoder_flush_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "us_decoder_set_training": (C.c_int, [C.c_void_p, C.c_int]),
+    "us_decoder_stale_inference_forms": (C.c_int, [C.c_void_p]),
     "us_decoder_num_weights": (C.c_int, [C.c_void_p]),
     "us_decoder_num_loaded": (C.c_int, [C.c_void_p]),
     "us_decoder_weight_key": (C.c_char_p, [C.c_void_p, C.c_int]),

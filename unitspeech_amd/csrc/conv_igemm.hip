@@ -1009,9 +1009,18 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         if (tm_pre1 < 0) { const char* e = getenv("US_TM_PRESPLIT_1X1"); tm_pre1 = e ? atoi(e) : 64; }
         if (a.ntaps == 1 && a.nphase <= 1) tm = tm_pre1;
       } else if (a.f16 == 1) {
-        // Winograd-domain GEMMs (all items of a frequency in one M range): the largest tile that still fills the chip
+        // Winograd-domain GEMMs (all items of a frequency in one M range).  Round 3's rule (256 rows whenever that leaves 384 workgroups)
+        // ignored wave quantisation: a B = 1 level-3 launch of 384 such workgroups is 1.5 per CU, i.e. two rounds for 1.5 rounds of work.
+        // Model: the busiest CU runs ceil(workgroups / 256) of them, each costing its rows; the 128-row form (two co-resident workgroups
+        // per CU) wins when that product is smaller (US_TM_MODEL=0: the old rule).  The tile never changes a result: every output element
+        // sums its K chunks in the same order in both forms.
+        static int tm_model = -1;
+        if (tm_model < 0) { const char* e = getenv("US_TM_MODEL"); tm_model = e ? atoi(e) : 1; }
         const long long per256 = (long long)((a.Hs * a.Ws + 255) / 256) * nt * a.B;
-        tm = per256 >= 384 ? 256 : 128;
+        const long long per128 = (long long)((a.Hs * a.Ws + 127) / 128) * nt * a.B;
+        const long long cost256 = ((per256 + 255) / 256) * 256, cost128 = ((per128 + 255) / 256) * 128;
+        if (tm_model) tm = cost128 < cost256 ? 128 : 256;
+        else tm = per256 >= 384 ? 256 : 128;
       } else {
         // direct convolutions (A split in the kernel): three co-resident 64-row workgroups per CU beat the larger tiles at every
         // U-Net shape (tools/conv_bench: 272 vs 251 vs 210 TFLOP/s on the level-0 3x3).  Never a function of the batch, so that

@@ -48,6 +48,12 @@ struct Slot {
   int level = -1;        // U-Net level of a ResnetBlock conv
   DevBuf wino_dg;        // ... and of the rotated, channel-swapped filter for the data gradient, [16][Cout/bk_dg][Cin][bk_dg]
   bool want_wino = false;
+  // inference-only second Winograd form with 4-wide tiles (wino4.hip): U of F(4x4,3x3) / F(2x4,3x3), [F][Cin/32][Cout][32] two-plane fp16.
+  // Packed at load unless the handle is in training mode (us_decoder_set_training: an optimiser step would otherwise re-pack 36 + 16 + 16
+  // matrices per convolution); `wino4_valid` says whether it matches the loaded weights -- a stale one is never used (F(2x2) serves)
+  DevBuf wino4;
+  int wino4_form = 0;
+  bool wino4_valid = false;
   bool dg_as_1x1 = false;  // RAW [Cout][Cin][1][1] tensor that also needs a dgrad pack (attention to_out)
   bool is_qkv = false;     // attention to_qkv: a second forward pack with the rows in qkv_src_row() order (ConvArgs::attn_part_ctx)
   DevBuf qkv_rows;         // ... in the same operand form as `buf` (f16x3 planes or fp32)
@@ -83,6 +89,7 @@ struct ResampleW {
 };
 
 int pick_bk(int cin) { return (cin % 32 == 0) ? 32 : 16; }
+constexpr const char* kWino4Default = "0,44,44,24";      // US_WINO4 (us_decoder::wino4_level_form)
 
 }  // namespace
 
@@ -132,6 +139,9 @@ struct us_decoder {
   bool wino_narrow = false; // US_WINO_NARROW=1: Winograd also for convolutions with cout <= dim below level 0 (add_resnet)
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
                             // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
+  // F(4x4,3x3) / F(2x4,3x3) Winograd in inference, per U-Net level: 0 = F(2x2) (wino.hip), 44, 24 (wino4.hip); US_WINO4="l0,l1,l2,l3"
+  int wino4_level_form[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool training = false;    // us_decoder_set_training
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
   // f16x3 operand range (kernels.h): one device word that every split ORs into when it meets a value beyond the fp16 range, and a
   // pinned host word us_range_status copies it to.  `exact`: the handle was created with US_CREATE_EXACT_FP32 (no f16x3 anywhere).
@@ -427,6 +437,13 @@ void plan(us_decoder* h, Arena& A, int Bp, int T, Buffers& b, bool train = false
     const size_t kout = train ? (size_t)std::max(c.cin, c.cout) : (size_t)c.cout;
     wv = std::max(wv, 16 * B * tiles * kin);
     wm = std::max(wm, 16 * B * tiles * kout);
+    if (!train && c.w->wino4.p) {
+      int t4h, t4w;
+      wino4_tiles(c.w->wino4_form, F >> l, T >> l, &t4h, &t4w);
+      const size_t f4 = (size_t)wino4_freqs(c.w->wino4_form) * B * t4h * t4w;
+      wv = std::max(wv, f4 * c.cin);
+      wm = std::max(wm, f4 * c.cout);
+    }
   };
   auto need_r = [&](const ResnetW& r) { need(r.c1, r.level); need(r.c2, r.level); };
   for (auto& d : h->downs) { need_r(d.r1); need_r(d.r2); }
@@ -446,6 +463,7 @@ struct EvalCtx {
   int Bm;
   int gn_slot = 0;
   int splitk_by_batch = 0;   // training contexts: see ConvArgs::splitk_by_batch
+  bool infer = false;        // an inference evaluation: the 4-wide Winograd forms (wino4.hip) may serve its 3x3 convolutions
 };
 
 double* next_stats(EvalCtx& e) {
@@ -506,11 +524,38 @@ struct WinoEpi {
   const float* add = nullptr; int add_ld = 0;
   bool mask_out = false;
 };
+// form4 / U4: the 4-wide-tile form of this convolution (Slot::wino4), or 0 / null
 hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int K, int N, int bk, int level, float* out, int out_ld,
-                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr, bool f16 = false) {
+                     const WinoEpi& ep, const WinoGnArgs* gn = nullptr, bool f16 = false, int form4 = 0, const float* U4 = nullptr) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
-  const int th = (H + 1) / 2, tw = (W + 1) / 2;
   Buffers& b = *e.b;
+  if (form4 && U4 && e.infer && !ep.add && !ep.mask_out && !(gn && gn->h_out) && (!gn || in_ld == K)) {
+    // F(4x4,3x3) / F(2x4,3x3): input transform (+ block1's GroupNorm), one GEMM over all items per frequency, output transform
+    int t4h, t4w;
+    wino4_tiles(form4, H, W, &t4h, &t4w);
+    const int nf = wino4_freqs(form4);
+    hipError_t err4 = launch_wino4_input(form4, in, in_ld, b.wino_v, e.Bp, H, W, K, gn, e.s);
+    if (err4 != hipSuccess) return err4;
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.f16 = 1;
+    a.in = b.wino_v; a.in_ld = K;
+    a.wt = U4; a.wt_bstride = (long long)N * K;
+    a.Hin = t4h; a.Win = t4w; a.Cin = K; a.Cout = N;
+    a.Hs = t4h; a.Ws = t4w; a.istride = 1;
+    a.bk = 32;
+    a.omask_bmod = 1;
+    a.zeros = e.h->zeros;
+    a.ntaps = 1;
+    a.set_tap(0, 0, 0, 0);
+    a.out = b.wino_m; a.out_ld = N;
+    a.B = nf; a.Hin = a.Hs = a.Hout = e.Bp * t4h; a.Wout = t4w; a.ostep = 1;
+    a.xcd_z = e.h->xcd_z && K >= 256 && N >= 256;
+    err4 = run_conv(e, a);
+    if (err4 != hipSuccess) return err4;
+    return launch_wino4_output(form4, b.wino_m, ep.bias, out, out_ld, ep.stats, e.Bp, H, W, N, e.s);
+  }
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
   // gn: `in` is block1's raw conv output (ld == K); its GroupNorm + Mish + time embedding are evaluated inside the transform
   // f16: U is in the f16x3 form and V is written the same way (two interleaved fp16 planes per value, same bytes and strides)
   hipError_t err = gn ? (in_ld == K ? launch_gn_wino_input(in, b.wino_v, e.Bp, H, W, K, *gn, e.s, f16) : hipErrorInvalidValue)
@@ -576,7 +621,9 @@ hipError_t conv3x3_wino(EvalCtx& e, const ConvW& w, const float* in, int in_ld, 
   WinoEpi ep;
   ep.bias = w.b ? w.b->buf.p : nullptr;
   ep.stats = stats;
-  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn, w.w->wino_f16);
+  const bool use4 = w.w->wino4.p && w.w->wino4_valid && w.w->wino_f16;
+  return wino_conv(e, in, in_ld, w.w->wino.p, w.cin, w.cout, w.w->bk, level, out, out_ld, ep, gn, w.w->wino_f16, use4 ? w.w->wino4_form : 0,
+                   use4 ? w.w->wino4.p : nullptr);
 }
 
 // in_split: `in` is the two-plane fp16 form written by gn_apply(out_split) (direct f16x3 convolutions only: direct_presplit())
@@ -1192,6 +1239,22 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   hipError_t e = conv_igemm_init();
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
+  {
+    // per-level 4-wide Winograd form of the inference path (wino4.hip), "l0,l1,l2,l3": 0 = F(2x2,3x3), 44 = F(4x4,3x3), 24 = F(2x4,3x3)
+    const char* w4 = getenv("US_WINO4");
+    std::string spec = w4 ? w4 : kWino4Default;
+    size_t pos = 0;
+    for (int l = 0; l < 8 && pos <= spec.size(); ++l) {
+      const size_t comma = spec.find(',', pos);
+      const std::string tok = spec.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+      const int f = tok.empty() ? 0 : atoi(tok.c_str());
+      h->wino4_level_form[l] = wino4_form_ok(f) ? f : 0;
+      if (comma == std::string::npos) break;
+      pos = comma + 1;
+    }
+    if (flags & US_CREATE_EXACT_FP32)
+      for (int l = 0; l < 8; ++l) h->wino4_level_form[l] = 0;
+  }
   if (const char* wl = getenv("US_WINO_NARROW")) h->wino_narrow = atoi(wl) != 0;
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS")) h->wino_fuse_min_wgs = atoll(wf);
   if (const char* wf = getenv("US_WINO_FUSE_MIN_WGS_SMALL")) h->wino_fuse_min_wgs_small = atoll(wf);
@@ -1262,9 +1325,14 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
       s->wino_f16 = s->shape[1] % 32 == 0;
       s->wino_dg_f16 = s->shape[0] % 32 == 0;
     }
+    if (ok && s->want_wino && s->wino_f16 && s->level >= 0 && s->level < 8 && wino4_form_ok(h->wino4_level_form[s->level]) && s->shape[0] % 8 == 0) {
+      s->wino4_form = h->wino4_level_form[s->level];
+      s->wino4.n = (size_t)wino4_freqs(s->wino4_form) * s->shape[0] * s->shape[1];
+      ok = hipMalloc(reinterpret_cast<void**>(&s->wino4.p), s->wino4.n * sizeof(float)) == hipSuccess;
+    }
     if (!ok) {
       g_last_error = "hipMalloc failed for weight store";
-      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); if (t->qkv_rows.p) (void)hipFree(t->qkv_rows.p); if (t->q_raw.p) (void)hipFree(t->q_raw.p); }
+      for (auto& t : h->slots) { if (t->buf.p) (void)hipFree(t->buf.p); if (t->dg.p) (void)hipFree(t->dg.p); if (t->wino.p) (void)hipFree(t->wino.p); if (t->wino_dg.p) (void)hipFree(t->wino_dg.p); if (t->wino4.p) (void)hipFree(t->wino4.p); if (t->qkv_rows.p) (void)hipFree(t->qkv_rows.p); if (t->q_raw.p) (void)hipFree(t->q_raw.p); }
       return US_EHIP;
     }
   }
@@ -1294,7 +1362,7 @@ int us_decoder_flush_weights(us_handle h, us_stream stream) {
 
 int us_decoder_destroy(us_handle h) {
   if (!h) return US_OK;
-  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); if (s->qkv_rows.p) (void)hipFree(s->qkv_rows.p); if (s->q_raw.p) (void)hipFree(s->q_raw.p); }
+  for (auto& s : h->slots) { if (s->buf.p) (void)hipFree(s->buf.p); if (s->dg.p) (void)hipFree(s->dg.p); if (s->wino.p) (void)hipFree(s->wino.p); if (s->wino_dg.p) (void)hipFree(s->wino_dg.p); if (s->wino4.p) (void)hipFree(s->wino4.p); if (s->qkv_rows.p) (void)hipFree(s->qkv_rows.p); if (s->q_raw.p) (void)hipFree(s->q_raw.p); }
   if (h->zeros) (void)hipFree(h->zeros);
   if (h->copy_tab_dev) (void)hipFree(h->copy_tab_dev);
   if (h->grad_tab_dev) (void)hipFree(h->grad_tab_dev);
@@ -1368,6 +1436,11 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
     case Kind::CONV_OIHW:
       // a conv that runs in the Winograd domain never reads its direct-form pack (conv3x3 takes the Winograd branch whenever
       // wino.p is set; every workspace plan of this handle then has the V/M scratch)
+      if (s->wino4.p) {
+        // the inference-only 4-wide form: packed now (from `data`, in stream order) unless the handle is in training mode
+        s->wino4_valid = !h->training;
+        if (s->wino4_valid) US_HIP(h, launch_wino4_pack_weight(s->wino4_form, data, s->wino4.p, (int)s->shape[0], (int)s->shape[1], st));
+      }
       if (s->wino.p && s->wino_f16) wino_f16(s->wino.p, false);
       else if (s->wino.p) US_HIP(h, launch_wino_pack_weight(data, s->wino.p, (int)s->shape[0], (int)s->shape[1], s->bk, st));
       else if (s->direct_f16) conv_f16(s->buf.p, (int)s->shape[0], (int)s->shape[1], (int)s->shape[2], (int)s->shape[3], true);
@@ -1394,6 +1467,19 @@ int us_decoder_load_weight(us_handle h, const char* key, const float* data, cons
   }
   s->loaded = true;
   return US_OK;
+}
+
+int us_decoder_set_training(us_handle h, int training) {
+  if (!h) { g_last_error = "null argument"; return US_EINVAL; }
+  h->training = training != 0;
+  return US_OK;
+}
+
+int us_decoder_stale_inference_forms(us_handle h) {
+  if (!h) return 0;
+  int n = 0;
+  for (auto& s : h->slots) n += (s->wino4.p && s->loaded && !s->wino4_valid) ? 1 : 0;
+  return n;
 }
 
 size_t us_workspace_bytes(us_handle h, int Bp, int T) {
@@ -1427,6 +1513,7 @@ int us_estimator_forward(us_handle h, const float* x, const float* mask, const f
   Buffers b;
   plan(h, A, Bp, T, b);
   EvalCtx e{h, static_cast<hipStream_t>(stream), &b, Bp, T, mask, Bp};
+  e.infer = true;
   RangeScope range_scope(h->range_flag);
   US_HIP(h, estimator_eval(e, x, Bp, mu, Bp, 0, t, spk, out, true));
   return US_OK;
@@ -1549,6 +1636,7 @@ int us_reverse_diffusion(us_handle h, const float* z, const float* mask, const f
     }
     const int n_text_uncond = use_t ? mb : 0;
     EvalCtx e{h, s, &bufs, Bp, T, mask_b, mb};
+    e.infer = true;
     const std::vector<size_t> base_off = bufs.tproj_off;     // per-resnet offsets of ONE evaluation (plan())
     std::vector<int> couts(h->n_resnets, 0);
     for (auto& d : h->downs) { couts[d.r1.index] = d.r1.cout; couts[d.r2.index] = d.r2.cout; }
@@ -1688,6 +1776,7 @@ int us_debug_block(us_handle h, int kind, const char* prefix, int level, const f
   Buffers b;
   plan(h, A, B, T, b);
   EvalCtx e{h, s, &b, B, T, mask, B};
+  e.infer = true;
   RangeScope range_scope(h->range_flag);
   US_HIP(h, hipMemsetAsync(b.stats, 0, b.stats_count * sizeof(double), s));
   std::vector<const ResnetW*> rs;

@@ -416,4 +416,17 @@ hipError_t launch_wino_output(const float* M, const float* bias, float* out, int
                               hipStream_t s, const WinoOutExtra* extra = nullptr);
 // f16x3 form of launch_wino_pack_weight (bk = 32): dst holds two interleaved fp16 planes per value, same size and row structure
 hipError_t launch_wino_pack_weight_f16(const float* src, float* dst, int Cout, int Cin, hipStream_t s, bool dgrad = false);
+
+// ---- Winograd F(MH x MW, 3x3) with 4-wide tiles (wino4.hip; inference, f16x3 operands only) -----------------------------------------
+// form = 10 * MH + MW: 44 = F(4x4,3x3), 36 frequencies, 2.25 Winograd-domain values per pixel; 24 = F(2x4,3x3), 24 frequencies, 3 per pixel
+// (F(2x2): 16 frequencies, 4 per pixel).  Tile grid th = ceil(H / MH) x tw = ceil(W / MW).  V: [F][B][th][tw][C] in the two-plane fp16 form;
+// U: [F][Cin/32][Cout][32] likewise (src: Conv2d OIHW 3x3); M: [F][B][th][tw][C] fp32.
+bool wino4_form_ok(int form);
+int wino4_freqs(int form);
+void wino4_tiles(int form, int H, int W, int* th, int* tw);
+// gn (optional): x is block1's raw conv output (ld == C) and d = (mish(GroupNorm(x)) * mask + temb) * mask is evaluated on the fly (h_out unsupported)
+hipError_t launch_wino4_input(int form, const float* x, int x_ld, float* V, int B, int H, int W, int C, const WinoGnArgs* gn, hipStream_t s);
+hipError_t launch_wino4_output(int form, const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
+                               hipStream_t s);
+hipError_t launch_wino4_pack_weight(int form, const float* src, float* dst, int Cout, int Cin, hipStream_t s);
 }  // namespace us

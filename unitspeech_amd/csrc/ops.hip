@@ -464,7 +464,10 @@ __global__ void pos_emb_kernel(const float* __restrict__ t, float* __restrict__ 
   const int r = i / half, k = i % half;
   // emb = exp(arange(half) * -(log(10000)/(half-1))); arg = scale * t * emb      (unitspeech.py:116-119)
   const float e = (float)(9.210340371976184 / (double)(half - 1));   // math.log(10000)/(half-1) rounded to fp32
-  const float freq = expf((float)k * -e);
+  // the exponential through fp64 and rounded once: correctly rounded, which is what torch's CPU exp returns for all 64 arguments of the
+  // full-size model; the device expf is an ulp off for some k, and an ulp of `freq` is an ulp of an argument near 1000: 3e-5 in sin / cos
+  // (tests/test_hip_parity_r2.py::test_time_embedding_vs_reference_golden)
+  const float freq = (float)exp((double)((float)k * -e));
   const float arg = scale * t[r] * freq;
   emb[(long long)r * dim + k] = sinf(arg);
   emb[(long long)r * dim + half + k] = cosf(arg);

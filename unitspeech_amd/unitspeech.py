@@ -162,6 +162,7 @@ class _Engine:
             _lib.check(self.lib.us_decoder_create_ex(C.byref(self.handle), C.byref(self.cfg), flags), None, "us_decoder_create_ex")
         self.device = device
         self.versions = {}
+        self.training = False
         self.weights_out_of_range = False
         self._range_host = None
         self._range_event = None
@@ -177,9 +178,16 @@ class _Engine:
         except Exception:
             pass
 
-    def sync_weights(self, named_tensors, device):
-        """Push every tensor whose storage or version changed since the last call."""
+    def sync_weights(self, named_tensors, device, training: bool = False):
+        """Push every tensor whose storage or version changed since the last call.  `training`: the call this sync precedes is a training
+        forward.  The library then skips the inference-only Winograd packs of the tensors it loads (us_decoder_set_training: an optimiser
+        step re-loads every tensor); the first inference call afterwards finds them stale and loads those weights once more."""
         self._create(device)
+        if bool(training) != getattr(self, "training", False):
+            _lib.check(self.lib.us_decoder_set_training(self.handle, 1 if training else 0), self.handle, "us_decoder_set_training")
+            self.training = bool(training)
+        if not training and self.lib.us_decoder_stale_inference_forms(self.handle) > 0:
+            self.versions.clear()
         with torch.cuda.device(device):
             stream = _stream()
             load = self.lib.us_decoder_load_weight
@@ -562,19 +570,20 @@ class GradLogPEstimator2d(BaseModule):
         else:
             weights += self._owner._own_weights()
         want_exact, range_check = self._flags()
+        x, mu, mask, t, spk = (_f32c(v, dev) for v in (x, mu, mask, t, spk_emb))
+        wants_grad = any(p.requires_grad for p in self.parameters()) or any(v.requires_grad for v in (x, mu, spk))
+        training = torch.is_grad_enabled() and wants_grad
 
         def engine(exact):
             e = self._get_engine(F, exact)
-            e.sync_weights(weights, dev)
+            e.sync_weights(weights, dev, training)
             if not e.exact and e.weights_out_of_range:      # a weight beyond the fp16 range: the default engine cannot hold this set
                 e = self._get_engine(F, True)
-                e.sync_weights(weights, dev)
+                e.sync_weights(weights, dev, training)
             return e
 
         eng = engine(want_exact)
-        x, mu, mask, t, spk = (_f32c(v, dev) for v in (x, mu, mask, t, spk_emb))
-        wants_grad = any(p.requires_grad for p in self.parameters()) or any(v.requires_grad for v in (x, mu, spk))
-        if torch.is_grad_enabled() and wants_grad:
+        if training:
             # training step (`loss_t` under autograd, unitspeech.py:393-405): gradients for the parameters and for x / mu /
             # spk_emb (a frozen decoder still passes d loss / d mu on to the caller's encoder, train_STEP2.py:130-131,299)
             named = list(self._named_weights())
