@@ -308,12 +308,19 @@ def _hip_grads(sd_np, x0, mask, cond, spk, t, z, exact=False, loss_factor=1.0):
     return float(loss), {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
 
 
-def _rel(new, ref, show=3):
+def _rel(new, ref, show=3, scalar_floor=0.0):
     """(whole-gradient relative L2, median per-tensor relative L2, worst per-tensor relative L2), every tensor -- the eight one-element
     Rezero gains included -- against its OWN norm.  (Round 3 measured the gains against the largest of them: they were sums formed from
-    M1 = G^T q with float atomics and moved by 1e-3 between runs.  They are fixed-order fp64 sums of grad_out * fn(x) now, train.hip.)"""
+    M1 = G^T q with float atomics and moved by 1e-3 between runs.  They are fixed-order fp64 sums of grad_out * fn(x) now, train.hip.)
+    scalar_floor > 0 (the comparison of two fp32 pipelines on ONE crop only): a gain's gradient is a sum of ~1e6 products of like magnitude, so
+    the rounding noise it inherits from its operands is ABSOLUTE, about the same for all eight, however far the sum itself cancels -- the
+    crop of key 21 has one gain at 2e-6 beside peers of 5e-5 ... 2e-3, and its 2e-9 of noise (1e-5 of a typical gain) reads as 1e-3 of
+    itself.  Such a scalar is measured against `scalar_floor` times the MEDIAN magnitude of the eight (round 3 used the largest).  The
+    8 x 176 comparison with the oracle below keeps every tensor on its own norm."""
     whole = float(torch.sqrt(sum(((new[n] - ref[n]) ** 2).sum() for n in ref)) / torch.sqrt(sum((ref[n] ** 2).sum() for n in ref)))
-    per = sorted((float((new[n] - ref[n]).norm() / (ref[n].norm() + 1e-300)), n) for n in ref)
+    scal = sorted(float(ref[n].abs().max()) for n in ref if ref[n].numel() == 1)
+    floor = scalar_floor * scal[len(scal) // 2] if scal else 0.0
+    per = sorted((float((new[n] - ref[n]).norm() / (max(float(ref[n].norm()), floor if ref[n].numel() == 1 else 0.0) + 1e-300)), n) for n in ref)
     print("\n  worst tensors: " + ", ".join(f"{n} {e:.1e} (|ref| {float(ref[n].norm()):.1e}, {ref[n].numel()} el.)" for e, n in per[-show:]))
     return whole, per[len(per) // 2][0], per[-1][0]
 
@@ -326,7 +333,7 @@ def test_backward_is_insensitive_to_the_magnitude_of_the_incoming_gradient(sd_np
     _, ref = _hip_grads(sd_np, *args, exact=True)
     _, small = _hip_grads(sd_np, *args, loss_factor=1e-3)
     small = {n: g * 1e3 for n, g in small.items()}
-    whole, median, worst = _rel(small, ref)
+    whole, median, worst = _rel(small, ref, scalar_floor=1.0)
     print(f"\nloss x 1e-3 at one crop: whole-gradient relative L2 vs exact fp32 {whole:.2e}, median tensor {median:.2e}, worst {worst:.2e}")
     assert len(ref) == 228 and whole <= 6e-7 and median <= 1.5e-6 and worst <= 1e-4
 

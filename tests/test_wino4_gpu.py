@@ -152,8 +152,8 @@ def test_training_mode_skips_the_inference_only_pack_and_inference_refreshes_it(
     loss.backward()
     with torch.no_grad():
         for n, p in model.named_parameters():
-            if "mid_block1.block1.block.0.weight" in n:
-                p.mul_(1.5)                                   # bumps the version: re-loaded by the next sync
+            if "mid_block1.block1.block.0.weight" in n:       # (a GroupNorm follows: scaling the weight would change nothing)
+                p.add_(torch.randn_like(p) * p.std())         # bumps the version: re-loaded by the next sync
     loss2, _ = model.compute_loss(x.clamp(-1, 1), mask, cond, spk)      # a training sync: the changed tensor's inference pack goes stale
     torch.cuda.synchronize()
     assert lib.us_decoder_stale_inference_forms(eng.handle) >= 1
@@ -163,4 +163,4 @@ def test_training_mode_skips_the_inference_only_pack_and_inference_refreshes_it(
     assert lib.us_decoder_stale_inference_forms(eng.handle) == 0
     sd2 = O.to_torch({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
     ref = O.estimator_forward(sd2, inp["z"], inp["mask"], inp["cond"], t.cpu(), inp["spk_emb"])
-    assert l1(after, ref) <= 2e-6 and l1(after, before) > 1e-4
+    assert l1(after, ref) <= 2e-6 and l1(after, before) > 1e-3

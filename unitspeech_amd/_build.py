@@ -13,6 +13,8 @@ SOURCES = ["conv_igemm.hip", "ops.hip", "attn.hip", "wino.hip", "wino4.hip", "tr
 # every source includes kernels.h; decoder.hip also includes the two .inc files (one stale check for all: a header edit is rare)
 HEADERS = ["kernels.h", "pack_f16.h", "wino4_coef.h", "train_host.inc", "train_abi.inc", os.path.join("..", "..", "include", "unitspeech_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# experiment builds only (timing ablations, -DUS_EXP_...): never set in production
+FLAGS += os.environ.get("UNITSPEECH_AMD_EXTRA_FLAGS", "").split()
 
 
 def source_fingerprint(names) -> str:

@@ -447,7 +447,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
           dma_slot(s0);
           total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, total[i][j], 0, 0, 0);
           dma_slot(s0 + 1);
+#ifndef US_EXP_TWO_PRODUCT      // experiment build: drop a_lo * b_hi, i.e. the A operand at fp16 precision
           total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, total[i][j], 0, 0, 0);
+#endif
           dma_slot(s0 + 2);
           if (!US_DMA_SPREAD && i == 0 && j == 0) dma_late();
         }
