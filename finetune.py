@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--decoder_checkpoint", type=str, default=None,
                     help="pre-trained decoder checkpoint to start from (train_STEP1.py:297-304 layout); --synthetic uses seeded weights otherwise")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--report_memory", action="store_true", help="print the allocated device memory with every progress line and the f16x3 range status at the end")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("CUDA/ROCm is not available: the HIP decoder has no CPU fallback")
@@ -167,6 +168,28 @@ def main():
     x_mask = torch.ones(1, 1, cond_x.shape[-1], device=device)
     attn = generate_path(duration, (x_mask.unsqueeze(-1) * mel_mask.unsqueeze(2)).squeeze(1))
 
+    def probe():
+        """--report_memory: the diffusion loss of the utterance's first segment at 8 FIXED (t, z) draws, outside the training run's random stream:
+        the same probe before and after the adaptation says whether it made progress (single iterations' losses vary 5x with their t)."""
+        cpu_state, dev_state = torch.get_rng_state(), torch.cuda.get_rng_state(device)
+        was_training = decoder.training
+        decoder.eval()
+        seg_mask = torch.ones(1, 1, segment, device=device)
+        a0 = attn[:, :, :segment]
+        cond_y = torch.matmul(a0.transpose(1, 2), cond_x.transpose(1, 2)).transpose(1, 2)          # unitspeech.py:484-486 for a crop at offset 0
+        tot = 0.0
+        with torch.no_grad():
+            for k in range(8):
+                torch.manual_seed(4321 + k)
+                loss, _ = decoder.compute_loss(mel[:, :, :segment], seg_mask, cond_y, spk_emb=spk_emb)
+                tot += float(loss)
+        decoder.train(was_training)
+        torch.set_rng_state(cpu_state)
+        torch.cuda.set_rng_state(dev_state, device)
+        return tot / 8
+
+    if args.report_memory:
+        print(f"probe loss before {probe():.5f}")
     graph = None
     if not args.no_graph:
         from unitspeech_amd.graph import FineTuneGraph
@@ -186,9 +209,14 @@ def main():
             opt.step(max_norm=1)
         if it % 50 == 0 or it == args.n_iters - 1:
             print(f"iter {it:4d}  diffusion loss {loss.item():.5f}")
+            if args.report_memory:
+                print(f"          allocated {torch.cuda.memory_allocated(device) >> 20} MiB")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{args.n_iters} iterations in {dt:.2f} s ({1e3 * dt / max(args.n_iters, 1):.1f} ms/iter)")
+    if args.report_memory:
+        print(f"range status {decoder.range_status()}")
+        print(f"probe loss after {probe():.5f}")
     os.makedirs(args.out_dir, exist_ok=True)
     path = os.path.join(args.out_dir, f"{args.ID}.pt")
     save_finetuned_checkpoint(path, decoder, spk_emb, mel_min, mel_max, base=base)           # finetune.py:167-173

@@ -123,3 +123,27 @@ def test_finetune_loss_trajectory_of_three_iterations_vs_oracle():
     assert len(got) == 3 and len(ref) == 3 and len(set(got)) == 3
     for a, b in zip(got, ref):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (got, ref)
+
+
+def test_config3_finetune_500_iterations_through_the_cli(tmp_path):
+    """BASELINE configs[3] at its stated length: `finetune.py` 500-iteration speaker adaptation (finetune.py:131-165 of the reference: crop,
+    t, z, forward, backward, clip_grad_norm_(1), Adam(2e-5)) on one synthetic 600-frame utterance.  Finite losses that go down, device memory
+    flat over the run, no f16x3 range event, a checkpoint in the reference's layout, and the wall time of the loop (<= 10 s)."""
+    import re
+    import torch
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "finetune.py"), "--synthetic", "--n_iters", "500", "--ID", "7", "--out_dir", str(tmp_path),
+                        "--report_memory"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = _losses(r.stdout)
+    assert len(losses) == 11 and all(np.isfinite(losses))            # iterations 0, 50, ..., 450, 499
+    pb, pa = (float(re.search(rf"probe loss {w} ([0-9.]+)", r.stdout).group(1)) for w in ("before", "after"))
+    assert np.isfinite(pa) and pa < pb, (pb, pa)                      # the same 8 fixed (t, z) draws before and after: the adaptation made progress
+    m = re.search(r"500 iterations in ([0-9.]+) s", r.stdout)
+    mem = [int(v) for v in re.findall(r"allocated (\d+) MiB", r.stdout)]
+    rng = re.search(r"range status (\d+)", r.stdout)
+    print(f"\nfinetune.py 500 iterations: {m.group(1)} s, probe loss {pb:.4f} -> {pa:.4f}, allocated MiB {mem[:2]} ... {mem[-1]}")
+    assert m and float(m.group(1)) <= 10.0
+    assert len(mem) >= 3 and mem[-1] <= mem[1] + 64                    # flat after the first iterations (graph capture, optimiser state)
+    assert rng and int(rng.group(1)) == 0
+    ck = torch.load(tmp_path / "7.pt", map_location="cpu")
+    assert set(ck) == {"model", "spk_emb", "mel_min", "mel_max"} and all(torch.isfinite(v).all() for v in ck["model"].values())

@@ -37,7 +37,8 @@ def main():
     spk3 = torch.cat([inp["spk_emb"], sd["spk_uncon"] / sd["spk_uncon"].norm(), inp["spk_emb"]], 0).to(DEV)
     t3 = torch.full((3,), 0.63, device=DEV)
     linp = {k: v.to(DEV) for k, v in G(synthetic_inputs(FULL, 1, T, seed=int(gold_l["seed"]), n_steps=50, lengths=[int(gold_l["lengths"][0])])).items()}
-    binp = {k: v.to(DEV) for k, v in G(synthetic_inputs(FULL, 1, T, seed=1000)).items()}
+    NB = int(os.environ.get("EXP_BATCH", "1"))
+    binp = {k: v.to(DEV) for k, v in G(synthetic_inputs(FULL, NB, T, seed=1000)).items()}
     ex = build(sd, exact=True)
     with torch.no_grad():
         ref_ex = ex.estimator(x3, mask3, mu3, t3, spk3)
@@ -56,13 +57,13 @@ def main():
                 m(binp["z"], binp["mask"], binp["cond"], binp["spk_emb"], 50, 1.0, 1.0, rng="philox", seed=1234)
             torch.cuda.synchronize()
             ts = []
-            for _ in range(6):
+            for _ in range(6 if NB == 1 else 3):
                 t0 = time.perf_counter()
                 m(binp["z"], binp["mask"], binp["cond"], binp["spk_emb"], 50, 1.0, 1.0, rng="philox", seed=1234)
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
         print(f"US_WINO4={cfg:14s} eval T=64 vs golden {e_g:.2e} vs fp64 {e_64:.2e} | eval T=1024 vs exact-fp32 engine {e_ex:.2e} | "
-              f"50-step T=1024 vs ref fp32 {e_l32:.2e} fp64 {e_l64:.2e} | decode {1e3 * float(np.median(ts)):.1f} ms = {T / float(np.median(ts)):.0f} frames/s",
+              f"50-step T=1024 vs ref fp32 {e_l32:.2e} fp64 {e_l64:.2e} | decode B={NB} {1e3 * float(np.median(ts)):.1f} ms = {NB * T / float(np.median(ts)):.0f} frames/s",
               flush=True)
         del m
         torch.cuda.empty_cache()

@@ -1017,11 +1017,13 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // per CU) wins when that product is smaller (US_TM_MODEL=0: the old rule).  The tile never changes a result: every output element
         // sums its K chunks in the same order in both forms.
         static int tm_model = -1;
-        if (tm_model < 0) { const char* e = getenv("US_TM_MODEL"); tm_model = e ? atoi(e) : 1; }
+        if (tm_model < 0) { const char* e = getenv("US_TM_MODEL"); tm_model = e ? atoi(e) : 15; }
         const long long per256 = (long long)((a.Hs * a.Ws + 255) / 256) * nt * a.B;
         const long long per128 = (long long)((a.Hs * a.Ws + 127) / 128) * nt * a.B;
         const long long cost256 = ((per256 + 255) / 256) * 256, cost128 = ((per128 + 255) / 256) * 128;
-        if (tm_model) tm = cost128 < cost256 ? 128 : 256;
+        // (tm_model = percent by which the 128-row form must undercut the 256-row one: the two-buffer four-wave kernel runs its rows
+        // slower than the three-buffer eight-wave one)
+        if (tm_model) tm = cost128 * (100 + tm_model) < cost256 * 100 ? 128 : 256;
         else tm = per256 >= 384 ? 256 : 128;
       } else {
         // direct convolutions (A split in the kernel): three co-resident 64-row workgroups per CU beat the larger tiles at every

@@ -68,14 +68,18 @@ hipError_t launch_stack_inputs(const float* x, int Bx, const float* mu, int Bmu,
 
 // ---------------------------------------------------------------------------------------------------
 // first layer: Conv2d(2, C, 3, pad 1) and res_conv Conv2d(2, C, 1) of downs.0.0 (unitspeech.py:48,66)
-// One workgroup = 32 consecutive frames of one mel row; the (3 x 34 x 2) masked input patch sits in LDS.
+// One workgroup = FC_TW consecutive frames of one mel row; the (3 x (FC_TW + 2) x 2) masked input patch sits in LDS.
+// Thread = (channel quad, run of consecutive frames): its 4 x 18 weights live in registers, the 3 x 3 x 2 window slides along the run (three
+// 8-byte LDS reads per frame), and every frame ends in ONE 16-byte store -- a wave writes whole 512-byte pixel rows.  Round 3's form
+// (thread = one channel: 18 broadcast LDS reads and a 4-byte store per output element) was bound by LDS instruction issue: 87 us for the
+// 126 MB it writes at 80 x 1024, 1.5 TB/s.  Same fmaf chain per output element (bias, then ci, ky, kx), so the same bits.
 // ---------------------------------------------------------------------------------------------------
-constexpr int FC_TW = 32;
+constexpr int FC_TW = 128;
 __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict__ in2, const float* __restrict__ w3,
                                                          const float* __restrict__ b3, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, float* __restrict__ y, float* __restrict__ r,
                                                          double* __restrict__ stats, int F, int T, int C) {
-  __shared__ float patch[3][FC_TW + 2][2];
+  __shared__ __attribute__((aligned(8))) float patch[3][FC_TW + 2][2];
   __shared__ double gred[kGroups][2];    // fp64: the merge order of the per-thread fp32 partials must not show in the result
   if (threadIdx.x < kGroups * 2) gred[threadIdx.x >> 1][threadIdx.x & 1] = 0.0;
   const int b = blockIdx.z, f = blockIdx.y, t0 = blockIdx.x * FC_TW;
@@ -88,46 +92,80 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
     patch[yy][xx][c] = v;
   }
   __syncthreads();
-  // thread = (output channel, slice of the 32 frames): with C = 128 the two halves of the block take 16 frames each (one thread per
-  // channel left half the block idle: 87 us of the 7.5 ms evaluation at 80 x 1024)
-  const int nsub = (C <= 128 && 256 % C == 0) ? 256 / C : 1;
-  const int sub = nsub > 1 ? tid / C : 0;
-  const int xlo = sub * (FC_TW / nsub), xhi = xlo + FC_TW / nsub;
-  for (int co = nsub > 1 ? tid % C : tid; co < C; co += 256) {
-    float w[18];
+  const int C4 = C >> 2;
+  const int qpb = C4 < 256 ? C4 : 256;              // quads handled side by side
+  const int nrun = 256 / qpb;                       // runs of frames side by side (threads beyond qpb * nrun idle: C / 4 not a divisor of 256)
+  const int flen = (FC_TW + nrun - 1) / nrun;
+  const int run = tid / qpb, ql = tid - run * qpb;
+  const int cg = C / kGroups;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  if (run < nrun) {
+    for (int q = ql; q < C4; q += qpb) {
+      const int co = 4 * q;
+      float w[4][18];
+      f32x4 bb, r0, r1, rb;
 #pragma unroll
-    for (int i = 0; i < 18; ++i) w[i] = w3[co * 18 + i];   // OIHW: [co][ci][ky][kx]
-    const float bb = b3[co], r0 = w1[co * 2], r1 = w1[co * 2 + 1], rb = b1[co];
-    float s1 = 0.f, s2 = 0.f;
-    for (int xx = xlo; xx < xhi; ++xx) {
-      if (t0 + xx >= T) break;
-      float acc = bb;
+      for (int k = 0; k < 4; ++k) {
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
+        for (int i = 0; i < 18; ++i) w[k][i] = w3[(co + k) * 18 + i];   // OIHW: [co][ci][ky][kx]
+        bb[k] = b3[co + k]; r0[k] = w1[(co + k) * 2]; r1[k] = w1[(co + k) * 2 + 1]; rb[k] = b1[co + k];
+      }
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+      const int xlo = run * flen, xhi = (xlo + flen < FC_TW ? xlo + flen : FC_TW);
+      // the window: win[ky][kx] = (channel 0, channel 1) of patch[ky][xx + kx]
+      f32x2 win[3][3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky) {
+        win[ky][1] = *reinterpret_cast<const f32x2*>(&patch[ky][xlo][0]);
+        win[ky][2] = *reinterpret_cast<const f32x2*>(&patch[ky][xlo + 1][0]);
+      }
+      for (int xx = xlo; xx < xhi; ++xx) {
+        if (t0 + xx >= T) break;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[ci * 9 + ky * 3 + kx], patch[ky][xx + kx][ci], acc);
-      long long p = ((long long)b * F + f) * T + t0 + xx;
-      y[p * C + co] = acc;
-      s1 += acc;
-      s2 += acc * acc;
-      if (r) r[p * C + co] = fmaf(r1, patch[1][xx + 1][1], fmaf(r0, patch[1][xx + 1][0], rb));
-    }
-    if (stats) {
-      atomicAdd(&gred[co / (C / kGroups)][0], (double)s1);
-      atomicAdd(&gred[co / (C / kGroups)][1], (double)s2);
+        for (int ky = 0; ky < 3; ++ky) {
+          win[ky][0] = win[ky][1];
+          win[ky][1] = win[ky][2];
+          win[ky][2] = *reinterpret_cast<const f32x2*>(&patch[ky][xx + 2][0]);
+        }
+        f32x4 acc = bb;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc[k] = fmaf(w[k][ci * 9 + ky * 3 + kx], win[ky][kx][ci], acc[k]);
+        const long long p = ((long long)b * F + f) * T + t0 + xx;
+        *reinterpret_cast<f32x4*>(y + p * C + co) = acc;
+        s1 += acc;
+        s2 += acc * acc;
+        if (r) {
+          f32x4 rv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rv[k] = fmaf(r1[k], win[1][1][1], fmaf(r0[k], win[1][1][0], rb[k]));
+          *reinterpret_cast<f32x4*>(r + p * C + co) = rv;
+        }
+      }
+      if (stats) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          atomicAdd(&gred[(co + k) / cg][0], (double)s1[k]);
+          atomicAdd(&gred[(co + k) / cg][1], (double)s2[k]);
+        }
+      }
     }
   }
   if (stats) {
     __syncthreads();
     if (threadIdx.x < kGroups * 2)
-      stat_add(stats, b, threadIdx.x >> 1, threadIdx.x & 1, blockIdx.x, gred[threadIdx.x >> 1][threadIdx.x & 1]);
+      stat_add(stats, b, threadIdx.x >> 1, threadIdx.x & 1, blockIdx.x + blockIdx.y * gridDim.x, gred[threadIdx.x >> 1][threadIdx.x & 1]);
   }
 }
 
 hipError_t launch_first_conv(const float* in2, const float* w3, const float* b3, const float* w1, const float* b1, float* y,
                              float* r, double* stats, int Bp, int F, int T, int C, hipStream_t s) {
+  if (C % 4 != 0) return hipErrorInvalidValue;
   dim3 grid((T + FC_TW - 1) / FC_TW, F, Bp);
   hipLaunchKernelGGL(first_conv_kernel, grid, dim3(256), 0, s, in2, w3, b3, w1, b1, y, r, stats, F, T, C);
   return hipGetLastError();
