@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int TN = 128;
+constexpr int TN = 128;      // columns per workgroup of the NB = 2 instantiations (host-side sizing)
 
 // One wave-wide LDS-DMA piece: 64 lanes x 16 bytes, lane l lands at lds_dst + 16*l.  `buffer_load_dwordx4 ... offen lds`
 // (SGPR descriptor + 32-bit per-lane byte offset + scalar offset) instead of `global_load_lds_dwordx4` (64-bit per-lane
@@ -75,8 +75,12 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // it goes through the DMA and the LDS image unchanged and each wave splits the 8 channels of a fragment into the two fp16 planes in
 // registers (v_cvt_pk_f16_f32, back-conversion, subtract, scale, v_cvt_pk_f16_f32: about 4 VALU operations per value, issued
 // beside the MFMAs).  Only the weights are pre-split.
-template <int BK, int WM, bool WINO, bool F16 = false, int NWM = 2, int NSTG = 2, bool ASPLIT = false>
+// NB = 32-column accumulator blocks per wave: 2 (tile TM x 128, what every launch used through round 3) or 1 (tile TM x 64: half the work per
+// workgroup, for Winograd-domain GEMMs whose 128-column grid is a fraction of a round of the chip -- a B = 1 level-3 launch is 384 workgroups on
+// 256 CUs, two rounds for 1.5 rounds of work; launch_conv_igemm decides)
+template <int BK, int WM, bool WINO, bool F16 = false, int NWM = 2, int NSTG = 2, bool ASPLIT = false, int NB = 2>
 __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int TN = 64 * NB;        // columns per workgroup: 2 waves (N) x NB blocks of 32
   constexpr int NW = 2 * NWM;        // waves per workgroup, NWM (M) x 2 (N)
   constexpr int TM = NWM * WM;       // rows (pixels) per workgroup
   constexpr int MB = WM / 32;        // 32-row MFMA blocks per wave along M
@@ -199,11 +203,11 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #define US_FLUSH_K 128
 #endif
   constexpr int kFlushSteps = US_FLUSH_K / BK;
-  f32x16 acc[MB][2], total[MB][2];
+  f32x16 acc[MB][NB], total[MB][NB];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; total[i][j][r] = 0.f; }
   int since_flush = 0;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // fragment read offsets (floats): row R, 16-byte chunk (2s+hh) ^ swz(R); swz only depends on the lane
   const int sw = (l32 / SWZ_DIV) % CPR;
   const int a_row = (wm * WM + l32) * BK;
-  const int b_row = TM * BK + (wn * 64 + l32) * BK;
+  const int b_row = TM * BK + (wn * (32 * NB) + l32) * BK;
 
 #ifndef US_PRIO_MODE
 #define US_PRIO_MODE 0
@@ -227,14 +231,14 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 #endif
   constexpr int NY = WINO ? 4 : 1;
-  f32x16 Y[NY][MB][2];       // WINO: the 2x2 output accumulators (dead otherwise)
+  f32x16 Y[NY][MB][NB];       // WINO: the 2x2 output accumulators (dead otherwise)
   if (WINO) {
 #pragma unroll
     for (int y = 0; y < NY; ++y)
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) Y[y][i][j][r] = 0.f;
   }
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) { acc[i][j][r] = __builtin_fmaf(total[i][j][r], 0x1p-11f, acc[i][j][r]); total[i][j][r] = 0.f; }
     }
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
           acc[i][j] += total[i][j];
 #pragma unroll
           for (int r = 0; r < 16; ++r) total[i][j][r] = 0.f;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Y[y][i][j][r] = __builtin_fmaf(cf[y], acc[i][j][r], Y[y][i][j][r]);
       }
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     since_flush = 0;
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // latency behind the barrier is covered by 8*MB MFMAs instead of idling the matrix pipe.
   constexpr int NS = F16 ? 2 : BK / 8;    // F16: two 16-deep steps per 32-channel chunk
   constexpr int NP = F16 ? 2 : 1;         // fp16 planes per operand
-  f32x4 fa0[MB * NP], fb0[2 * NP], fa1[MB * NP], fb1[2 * NP];
+  f32x4 fa0[MB * NP], fb0[NB * NP], fa1[MB * NP], fb1[NB * NP];
   float amax = 0.f;                       // ASPLIT: largest magnitude this wave split (range report after the loop)
   auto load_frags = [&](f32x4* fa, f32x4* fb, const float* base, int s_) {
     if (F16) {
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #ifdef US_ABL_LDS      // timing experiment: half the fragment reads (the lo planes alias the hi planes; results are wrong)
         if (p == 1 && !ASPLIT) {
           for (int i = 0; i < MB; ++i) fa[i * 2 + 1] = fa[i * 2];
-          fb[1] = fb[0]; fb[3] = fb[2];
+          for (int nb = 0; nb < NB; ++nb) fb[nb * 2 + 1] = fb[nb * 2];
           continue;
         }
 #endif
@@ -334,8 +338,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < MB; ++i) fa[i * 2 + p] = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + co);
         }
-        fb[p] = *reinterpret_cast<const f32x4*>(base + b_row + co);
-        fb[2 + p] = *reinterpret_cast<const f32x4*>(base + b_row + 32 * BK + co);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fb[nb * 2 + p] = *reinterpret_cast<const f32x4*>(base + b_row + nb * 32 * BK + co);
       }
       if (ASPLIT) {
         // fp32 row: the same 8 channels are two 16-byte chunks of 4 floats; split them here
@@ -367,8 +371,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     const int co = ((2 * s_ + hh) ^ sw) * 4;
 #pragma unroll
     for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f32x4*>(base + a_row + i * 32 * BK + co);
-    fb[0] = *reinterpret_cast<const f32x4*>(base + b_row + co);
-    fb[1] = *reinterpret_cast<const f32x4*>(base + b_row + 32 * BK + co);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) fb[nb] = *reinterpret_cast<const f32x4*>(base + b_row + nb * 32 * BK + co);
     // keep the reads AHEAD of the MFMAs that follow in program order (hipcc otherwise sinks them behind the
     // MFMA block and waits for them at once, exposing the LDS latency)
 #ifndef US_NO_SCHEDBAR
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #define US_DMA_SPREAD 1
 #endif
   constexpr int NPIECE = IA + IB;
-  constexpr int SLOTS = 12 * MB;                       // F16 MFMAs of a wave per chunk
+  constexpr int SLOTS = 6 * MB * NB;                  // F16 MFMAs of a wave per chunk
   constexpr int PSTRIDE = SLOTS / NPIECE > 0 ? SLOTS / NPIECE : 1;
   unsigned pend_ach = 0, pend_wb = 0;
   auto dma_piece = [&](int k) {
@@ -439,10 +443,10 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
           const half8 ah = __builtin_bit_cast(half8, fa[i * 2]), al = __builtin_bit_cast(half8, fa[i * 2 + 1]);
           const half8 bh = __builtin_bit_cast(half8, fb[j * 2]), bl = __builtin_bit_cast(half8, fb[j * 2 + 1]);
-          const int s0 = phase * (SLOTS / 2) + (i * 2 + j) * 3;
+          const int s0 = phase * (SLOTS / 2) + (i * NB + j) * 3;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
           dma_slot(s0);
           total[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, total[i][j], 0, 0, 0);
@@ -462,8 +466,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[0][j], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[1][j], acc[i][1], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[nb][j], acc[i][nb], 0, 0, 0);
       }
 #if US_PRIO_MODE == 2
     __builtin_amdgcn_s_setprio(0);
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
           total[i][j] += acc[i][j];
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NB; ++j) {
         if (F16) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(total[i][j][r], 0x1p-11f, acc[i][j][r]);
@@ -658,14 +662,14 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // GroupNorm partial sums: fp32 per lane, except in the Winograd form where they are kept in fp64 so that the fused and the
   // separate output transform (chosen by launch geometry, i.e. by the batch) agree to fp64 rounding
   typedef typename std::conditional<WINO, double, float>::type stat_t;
-  stat_t gsum[2] = {0, 0}, gsq[2] = {0, 0};
+  stat_t gsum[NB] = {}, gsq[NB] = {};
 #ifdef US_CONV_ABLATE
   if (a.debug & 8) {       // timing ablation: no epilogue at all (keep the accumulators alive)
     float keep = 0.f;
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
     if (keep == 1.2345e-30f) a.out[0] = keep;
@@ -683,8 +687,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
         const int m = m0 + wm * WM + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (m < Ms) {
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const int n = n0 + wn * 64 + nb * 32 + l32;
+          for (int nb = 0; nb < NB; ++nb) {
+            const int n = n0 + wn * (32 * NB) + nb * 32 + l32;
             if (n < a.Cout) slab[(long long)m * a.Cout + n] = acc[mb][nb][r];
           }
         }
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // wave instruction, 4x fewer memory instructions than the native layout (the epilogue was half the time of the K=128
   // 1x1 convolutions and 11 % of the level-0 3x3s).
   __syncthreads();                                   // every wave is done with the operand buffers
-  if constexpr (!WINO && MB == 1) {
+  if constexpr (!WINO && MB == 1 && NB == 2) {
     if (a.attn_part_ctx && n0 >= a.attn_q_cols) {
       // to_qkv column tiles 1 / 2: this wave's two 32-column blocks are k_h and v_h of head h for 32 of the tile's 64 rows
       // (qkv_src_row).  Linear attention (unitspeech/unitspeech.py:91-92): k = softmax over ALL n positions, ctx = k v^T; here the
@@ -761,18 +765,18 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // bias of this wave's two 32-column blocks, loaded ONCE: a global load inside the block loop would make every block wait
   // (vmcnt retires in order) for the previous block's stores to reach memory
   bool out_over = false;          // out_split: a stored value beyond the fp16 range
-  float bias_col[2];
-  f32x4 bias_quad[2];
+  float bias_col[NB];
+  f32x4 bias_quad[NB];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int ncol = n0 + wn * 64 + nb * 32;
+  for (int nb = 0; nb < NB; ++nb) {
+    const int ncol = n0 + wn * (32 * NB) + nb * 32;
     bias_col[nb] = (a.bias && ncol + l32 < a.Cout) ? a.bias[ncol + l32] : 0.f;
     bias_quad[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.bias && ncol + tc4 < a.Cout) bias_quad[nb] = *reinterpret_cast<const f32x4*>(a.bias + ncol + tc4);
   }
 #pragma unroll
   for (int yi = 0; yi < NY; ++yi) {
-  const f32x16 (&A)[MB][2] = WINO ? Y[yi] : acc;
+  const f32x16 (&A)[MB][NB] = WINO ? Y[yi] : acc;
   const int oy0 = WINO ? (yi >> 1) : a_oy0, ox0 = WINO ? (yi & 1) : a_ox0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -780,8 +784,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     int yb = 0, xb = 0;
     if (need_xy) { yb = m_base / a.Ws; xb = m_base - yb * a.Ws; }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int ncol = n0 + wn * 64 + nb * 32;
+    for (int nb = 0; nb < NB; ++nb) {
+      const int ncol = n0 + wn * (32 * NB) + nb * 32;
       {   // GroupNorm sums in the native layout (this lane's column, its 16 rows)
         const int n = ncol + l32;
         const float bv = bias_col[nb];
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     // GroupNorm(8) partial sums of the conv output (pre-alpha/add/mask); Cout/8 is a power of two (host-checked)
     const int cg = a.Cout / kGroups;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       stat_t s1 = gsum[nb], s2 = gsq[nb];
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
         s1 += __shfl_xor(s1, off);
         s2 += __shfl_xor(s2, off);
       }
-      const int n = n0 + wn * 64 + nb * 32 + l32;
+      const int n = n0 + wn * (32 * NB) + nb * 32 + l32;
       if (hh == 0 && (l32 % seg) == 0 && n < a.Cout) {
         stat_add(a.stats, b, n / cg, 0, bx, (double)s1);
         stat_add(a.stats, b, n / cg, 1, bx, (double)s2);
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
   }
 }
 
-static size_t lds_bytes(int bk, int tm, int nstg = 2) { return (size_t)nstg * (tm + TN) * bk * sizeof(float); }
+static size_t lds_bytes(int bk, int tm, int nstg = 2, int tn = TN) { return (size_t)nstg * (tm + tn) * bk * sizeof(float); }
 
 template <int BK, int WM, bool WINO, bool F16 = false, int NWM = 2, int NSTG = 2, bool ASPLIT = false>
 static hipError_t set_attr() {
@@ -951,6 +955,8 @@ hipError_t conv_igemm_init() {
   if ((e = set_attr<32, 32, true>()) != hipSuccess) return e;
   if ((e = set_attr<32, 64, false, true>()) != hipSuccess) return e;
   if ((e = set_attr<32, 64, false, true, 4, 3>()) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<32, 64, false, true, 4, 3, false, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(32, 256, 3, 64))) != hipSuccess) return e;
   if ((e = set_attr<32, 64, false, true, 4, 3, true>()) != hipSuccess) return e;
   if ((e = set_attr<32, 64, false, true, 2, 2, true>()) != hipSuccess) return e;
   if ((e = set_attr<32, 32, false, true, 2, 2, true>()) != hipSuccess) return e;
@@ -991,7 +997,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     g_tm64_threshold = e ? atoi(e) : (1 << 30);
   }
   const int Ms = a.Hs * a.Ws;
-  const int nt = (a.Cout + TN - 1) / TN;
+  int tn = TN;                        // 64: the half-width tile of the Winograd-domain GEMMs (conv_igemm_kernel<.., NB = 1>), chosen below
+  int nt = (a.Cout + TN - 1) / TN;
   int tm = a.tm;
   if (a.f16) {
     // f16x3: the weights are pre-split; f16 = 1: so is the A operand (Winograd-domain GEMMs, planes written by the input
@@ -1025,6 +1032,18 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // slower than the three-buffer eight-wave one)
         if (tm_model) tm = cost128 * (100 + tm_model) < cost256 * 100 ? 128 : 256;
         else tm = per256 >= 384 ? 256 : 128;
+        // ... and 256 rows x 64 columns: half the work per workgroup at the eight-wave kernel's rate per row (each wave keeps one 32-column
+        // block: 12 instead of 24 MFMAs per chunk against the same A fragments).  B = 1 level-3 launch, 768 of them: three rounds of half
+        // work instead of two of full -- measured 94.5 -> 89.5 us, a third of what the model promises: the half-width kernel runs its work ~15 %
+        // slower.  US_TN64=0 switches it off; the margin (percent) covers the thinner MFMA : LDS-read ratio.
+        static int tn64 = -1;
+        if (tn64 < 0) { const char* e = getenv("US_TN64"); tn64 = e ? atoi(e) : 25; }
+        if (tn64 > 0 && a.Cout % 64 == 0 && a.Cin >= 1024) {      // (K = 256 ... 512: twice the prologues and epilogues per unit of work cost more than the rounds saved: measured 34 -> 38 us, 102 -> 120 us)
+          const long long per64 = (long long)((a.Hs * a.Ws + 255) / 256) * ((a.Cout + 63) / 64) * a.B;
+          const long long cost64 = ((per64 + 255) / 256) * 128;
+          // against the 256 x 128 form (the 128-row one measured no better than it wherever the model preferred it)
+          if (cost64 * (100 + tn64) < cost256 * 100) { tm = 256; tn = 64; nt = (a.Cout + 63) / 64; }
+        }
       } else {
         // direct convolutions (A split in the kernel): three co-resident 64-row workgroups per CU beat the larger tiles at every
         // U-Net shape (tools/conv_bench: 272 vs 251 vs 210 TFLOP/s on the level-0 3x3).  Never a function of the batch, so that
@@ -1095,6 +1114,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   } else if (a.f16) {
     if (a.wino_out && !(a.debug & 128)) hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true, true, 2, 3>), grid, dim3(256), lds_bytes(32, 64, 3), s, a);
     else if (a.wino_out) hipLaunchKernelGGL((conv_igemm_kernel<32, 32, true, true>), grid, dim3(256), lds, s, a);
+    else if (tm == 256 && tn == 64) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 4, 3, false, 1>), grid, dim3(512), lds_bytes(32, 256, 3, 64), s, a);
     else if (tm == 256) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true, 4, 3>), grid, dim3(512), lds_bytes(32, 256, 3), s, a);
     else if (tm == 128) hipLaunchKernelGGL((conv_igemm_kernel<32, 64, false, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<32, 32, false, true>), grid, dim3(256), lds, s, a);
