@@ -446,3 +446,15 @@ def test_backward_needs_no_zero_fill_for_the_convolution_weight_gradients(sd_np)
     assert all(torch.isfinite(g).all() for g in new.values())
     whole, _, worst = _rel(new, ref)
     assert whole <= 2e-7 and worst <= 1e-4
+
+
+def test_winograd_split_k_slabs_give_the_same_gradients(sd_np, monkeypatch):
+    """US_WINO_SPLITK=1 (off by default: measured slower): the Winograd-domain GEMMs of a one-crop training pass slice K and the
+    output transform sums the raw slabs in slice order.  Same loss, gradients equal up to the regrouping of the K sum."""
+    args = _crops(1, 176, key=91)
+    l0, ref = _hip_grads(sd_np, *args)
+    monkeypatch.setenv("US_WINO_SPLITK", "1")
+    l1_, got = _hip_grads(sd_np, *args)
+    whole, median, worst = _rel(got, ref, scalar_floor=1.0)
+    print(f"\nWinograd split-K slabs vs single pass: loss {l1_:.7f} / {l0:.7f}, whole-gradient relative L2 {whole:.2e}, median tensor {median:.2e}, worst {worst:.2e}")
+    assert abs(l1_ - l0) <= 2e-6 * max(1.0, abs(l0)) and whole <= 6e-7 and worst <= 1e-4

@@ -1004,7 +1004,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     // f16x3: the weights are pre-split; f16 = 1: so is the A operand (Winograd-domain GEMMs, planes written by the input
     // transforms); f16 = 2: A is a plain fp32 activation tensor, split in the kernel (any tap geometry)
     if (a.bk != 32) return hipErrorInvalidValue;
-    if (a.f16 == 1 && !a.direct_presplit && a.ntaps == 1 && a.istride == 1 && !a.bias && !a.add) a.splitk_ws = nullptr;    // Winograd-domain GEMMs
+    if (a.f16 == 1 && !a.direct_presplit && a.ntaps == 1 && a.istride == 1 && !a.bias && !a.add && !a.splitk_raw) a.splitk_ws = nullptr;    // Winograd-domain GEMMs
     if (tm == 0 && g_f16_tm > 0) tm = g_f16_tm;
     if (tm == 0) {
       if (a.f16 == 1 && (a.ntaps > 1 || a.direct_presplit)) {
@@ -1104,6 +1104,19 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (k > 32) k = 32;
     if (k >= 2 && k * (long long)a.B * Ms * a.Cout <= a.splitk_ws_floats) a.ksplit = (int)k;
   }
+  if (a.splitk_raw) {
+    // Winograd-domain GEMMs of one fine-tune crop: 16 frequencies x (1 row tile x 8 column tiles) = 128 workgroups walking 32 chunks each
+    // (33 us, 26 such launches per iteration).  Slice K so that the launch is ~3 workgroups per CU; the output transform sums the slabs.
+    a.ksplit = 1;
+    if (g_splitk && a.splitk_ws && !a.wino_out && !a.out_split && !a.stats && !a.add && !a.bias && tiles < 384 && S_all >= 16) {
+      long long k = (768 + tiles - 1) / tiles;
+      if (k > S_all / 4) k = S_all / 4;
+      if (k > 8) k = 8;
+      while (k >= 2 && k * (long long)a.B * Ms * a.Cout > a.splitk_ws_floats) --k;
+      if (k >= 2) a.ksplit = (int)k;
+    }
+    if (a.ksplit_out) *a.ksplit_out = a.ksplit;
+  }
   a.nt = nt;
   dim3 grid(mt * a.ksplit * nt, 1, a.B * (a.nphase > 1 ? a.nphase : 1));
   const size_t lds = lds_bytes(a.bk, tm);
@@ -1131,7 +1144,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm_kernel<16, 64, false>), grid, dim3(256), lds, s, a);
   else
     hipLaunchKernelGGL((conv_igemm_kernel<16, 32, false>), grid, dim3(256), lds, s, a);
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && !a.splitk_raw) {
     long long total = (long long)Ms * (a.Cout / 4);
     int blocks = (int)((total + 1023) / 1024);
     if (blocks < 1) blocks = 1;

@@ -142,6 +142,7 @@ struct us_decoder {
   // F(4x4,3x3) / F(2x4,3x3) Winograd in inference, per U-Net level: 0 = F(2x2) (wino.hip), 44, 24 (wino4.hip); US_WINO4="l0,l1,l2,l3"
   int wino4_level_form[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool training = false;    // us_decoder_set_training
+  bool wino_splitk = false; // US_WINO_SPLITK=1: K-sliced Winograd-domain GEMMs in training passes (wino_conv)
   float* zeros = nullptr;   // zero page read by out-of-image convolution taps
   // f16x3 operand range (kernels.h): one device word that every split ORs into when it meets a value beyond the fp16 range, and a
   // pinned host word us_range_status copies it to.  `exact`: the handle was created with US_CREATE_EXACT_FP32 (no f16x3 anywhere).
@@ -608,11 +609,21 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
   // whole frequencies per XCD pay where a frequency's workgroups share operand tiles (nt > 1 column tiles re-reading A, K long enough
   // for the shared reads to matter): with 128 input or output channels the same placement measured 2-20 % SLOWER
   a.xcd_z = e.h->xcd_z && K >= 256 && N >= 256;
+  // training passes (one crop: a frequency's GEMM is a single row tile): K may be sliced, the output transform sums the slabs (ConvArgs::splitk_raw)
+  int ks = 1;
+  // (measured NEGATIVE at one crop: fine-tune iteration 8.57 -> 9.05 ms -- the chains these launches sit on are paced by launch latency, and
+  // 4-6x the workgroups take the chip from the weight-gradient stream beside them -- so it is off unless US_WINO_SPLITK=1)
+  if (e.splitk_by_batch && e.h->wino_splitk && f16) {
+    a.splitk_raw = 1;
+    a.splitk_ws = b.splitk; a.splitk_ws_floats = (long long)b.splitk_floats;
+    a.ksplit_out = &ks;
+  }
   err = run_conv(e, a);
   if (err != hipSuccess) return err;
   WinoOutExtra x{};
   x.add = ep.add; x.add_ld = ep.add_ld;
   if (ep.mask_out) { x.mask = e.mask; x.mask_ld = e.T; x.mask_step = 1 << level; x.mask_bmod = e.Bm; }
+  if (ks > 1) return launch_wino_output(b.splitk, ep.bias, out, out_ld, ep.stats, e.Bp, H, W, N, e.s, &x, ks, 16LL * e.Bp * th * tw * N);
   return launch_wino_output(b.wino_m, ep.bias, out, out_ld, ep.stats, e.Bp, H, W, N, e.s, &x);
 }
 
@@ -1239,6 +1250,7 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   hipError_t e = conv_igemm_init();
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
+  if (const char* ws = getenv("US_WINO_SPLITK")) h->wino_splitk = atoi(ws) != 0;
   {
     // per-level 4-wide Winograd form of the inference path (wino4.hip), "l0,l1,l2,l3": 0 = F(2x2,3x3), 44 = F(4x4,3x3), 24 = F(2x4,3x3)
     const char* w4 = getenv("US_WINO4");

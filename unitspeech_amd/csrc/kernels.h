@@ -122,6 +122,9 @@ struct ConvArgs {
   int attn_q_cols;       // kHidden: column tile 0 is q and is stored; 0: the launch computes k | v only (Cout = 2 * kHidden, nothing stored:
                          // the caller folds W_q into the output projection, launch_attn_wtotal)
   int wt_rows;           // rows per K-chunk of the packed weight when the launch uses only Cout of them (0: Cout)
+  int splitk_raw;        // Winograd-domain GEMMs of a training pass (B = frequencies): the launcher may slice K and leave the raw slabs
+                         // [ks][B][Ms][Cout] in splitk_ws for the output transform to sum in slice order (no finish launch); the slice count
+  int* ksplit_out;       // ... is returned here (host pointer; 1 = `out` was written as usual)
   float* out2;           // optional second output, pixel-indexed like out (ld out2_ld): acc + bias BEFORE alpha / add / mask.  Training keeps
   int out2_ld;           // the Rezero branch's fn(x) this way: the gain's gradient is sum(grad_out * fn(x)) (unitspeech/unitspeech.py:36-43)
 #ifdef US_STAMP
@@ -412,8 +415,9 @@ struct WinoOutExtra {
   const float* add; int add_ld;                          // pixel-indexed like out
   const float* mask; int mask_ld, mask_step, mask_bmod;  // column ox reads mask[ox * mask_step]
 };
+// nslab > 1: M is nslab split-K slabs of the product, slab_stride floats apart, summed here in slab order (ConvArgs::splitk_raw)
 hipError_t launch_wino_output(const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
-                              hipStream_t s, const WinoOutExtra* extra = nullptr);
+                              hipStream_t s, const WinoOutExtra* extra = nullptr, int nslab = 1, long long slab_stride = 0);
 // f16x3 form of launch_wino_pack_weight (bk = 32): dst holds two interleaved fp16 planes per value, same size and row structure
 hipError_t launch_wino_pack_weight_f16(const float* src, float* dst, int Cout, int Cin, hipStream_t s, bool dgrad = false);
 

@@ -209,7 +209,8 @@ hipError_t launch_gn_wino_input(const float* y, float* V, int B, int H, int W, i
 }
 
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ out,
-                                                          int out_ld, double* __restrict__ stats, int B, int H, int W, int C, WinoOutExtra x) {
+                                                          int out_ld, double* __restrict__ stats, int B, int H, int W, int C, WinoOutExtra x,
+                                                          int nslab, long long slab_stride) {
   __shared__ double s_g[kGroups][2];
   const int C4 = C >> 2;
   const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
@@ -243,7 +244,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) m[r][q] = *reinterpret_cast<const f32x4*>(mb + (long long)(r * 4 + q) * plane);
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(mb + (long long)(r * 4 + q) * plane);
+        for (int k = 1; k < nslab; ++k) v += *reinterpret_cast<const f32x4*>(mb + k * slab_stride + (long long)(r * 4 + q) * plane);      // split-K slabs, in slice order
+        m[r][q] = v;
+      }
     // Y = A^T M A, accumulated frequency by frequency in the order f = 0..15 with coefficients At[r][f/4] * At[q][f%4]
     // (At = [1 1 1 0; 0 1 -1 -1]) -- the same sequence of additions as the fused form inside conv_igemm_kernel<.., true>,
     // so a result does not depend on which form a launch geometry selects
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 }
 
 hipError_t launch_wino_output(const float* M, const float* bias, float* out, int out_ld, double* stats, int B, int H, int W, int C,
-                              hipStream_t s, const WinoOutExtra* extra) {
+                              hipStream_t s, const WinoOutExtra* extra, int nslab, long long slab_stride) {
   if (C % 4 != 0 || out_ld % 4 != 0 || C % kGroups != 0 || (extra && extra->add && extra->add_ld % 4 != 0)) return hipErrorInvalidValue;
   WinoOutExtra x{};
   if (extra) x = *extra;
@@ -329,7 +334,7 @@ hipError_t launch_wino_output(const float* M, const float* bias, float* out, int
   int blocks = (int)((per_item + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wino_output_kernel, dim3(blocks, B), dim3(256), 0, s, M, bias, out, out_ld, stats, B, H, W, C, x);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(blocks, B), dim3(256), 0, s, M, bias, out, out_ld, stats, B, H, W, C, x, nslab < 1 ? 1 : nslab, slab_stride);
   return hipGetLastError();
 }
 

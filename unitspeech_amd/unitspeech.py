@@ -755,7 +755,13 @@ class UnitSpeech(BaseModule):
         def run(e):
             out = torch.empty_like(z)
             with torch.cuda.device(dev):
+                # utterances per launch: 8 (21.9 GB of workspace per CFG triple set at T = 1024), 16 from 16 utterances up where that much
+                # memory is free (+1.2 % at B = 64: profiles/r04_bench_B64.json); an item's result never depends on it (bit for bit)
                 mb = self.micro_batch if self.micro_batch > 0 else 8
+                if self.micro_batch <= 0 and B >= 16:
+                    free, _ = torch.cuda.mem_get_info(dev)
+                    if e.lib.us_sampler_workspace_bytes(e.handle, 16, T, n_cfg) <= free // 2 + (e.workspace.numel() if e.workspace is not None else 0):
+                        mb = 16
                 mb = min(mb, B)
                 nbytes = e.lib.us_sampler_workspace_bytes(e.handle, mb, T, n_cfg)
                 wsb = e.get_workspace(nbytes, dev)
