@@ -15,6 +15,8 @@ ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--bp", type=int, default=3)
 ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--wino-min-level", type=int, default=1, help="levels >= this run their 3x3 convs as Winograd (US_WINO_MIN_LEVEL)")
+ap.add_argument("--wino4", default=__import__("os").environ.get("US_WINO4", "0,44,44,24"),
+                help="per-level 4-wide Winograd form of the inference path (US_WINO4): 0 = F(2x2), 44 = F(4x4), 24 = F(2x4)")
 ap.add_argument("--wino-narrow", action="store_true", help="US_WINO_NARROW=1: Winograd also where cout <= dim (the last up level)")
 ap.add_argument("--no-wtotal", action="store_true", help="US_ATTN_WTOTAL=0: q is computed and stored at every level")
 ap.add_argument("--no-split-copy", action="store_true", help="US_SPLIT_COPY=0: res_conv stays the last launch of every ResnetBlock")
@@ -33,10 +35,25 @@ def npx(l):
 seq = []
 
 
-def conv(name, l_out_pixels, cin, cout, taps, wino=False):
-    # wino: executed as Winograd F(2x2,3x3): 16 tile GEMMs for 4 output pixels instead of 9 taps each -> 2.25x fewer FLOPs
+W4 = [int(v or 0) for v in a.wino4.split(",")] + [0] * 8
+# multiplications per output pixel: direct 9; F(2x2) 16 / 4; F(2x4) 24 / 8; F(4x4) 36 / 16 (tile counts rounded up per axis)
+WINO_DIV = {0: 2.25, 24: 3.0, 44: 4.0}
+WINO_TAG = {0: "[W]", 24: "[W24]", 44: "[W44]"}
+
+
+def conv(name, l_out_pixels, cin, cout, taps, wino=False, level=0):
+    # wino: executed as Winograd F(2x2,3x3) / F(2x4,3x3) / F(4x4,3x3): 4 / 3 / 2.25 multiplications per output pixel instead of 9.
+    # GFLOP = what the MFMA units execute for whole tiles (the launch's own count, tile padding included)
     fl = 2.0 * BP * l_out_pixels * cin * cout * taps
-    seq.append((name + (" [W]" if wino else ""), fl / 2.25 if wino else fl, l_out_pixels, cin, cout, taps))
+    tag = ""
+    if wino:
+        form = W4[level]
+        h, w = F >> level, T >> level
+        mh, mw = (form // 10, form % 10) if form else (2, 2)
+        tiles = -(-h // mh) * -(-w // mw)
+        fl = 2.0 * BP * tiles * (mh + 2) * (mw + 2) * cin * cout
+        tag = " " + WINO_TAG[form]
+    seq.append((name + tag, fl, l_out_pixels, cin, cout, taps))
 
 
 def resnet(name, l, cin, cout, first=False):
@@ -47,8 +64,8 @@ def resnet(name, l, cin, cout, first=False):
     if res_first:
         conv(f"{name}.res 1x1 {cin}->{cout} L{l}", npx(l), cin, cout, 1)
     if not first:
-        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=wino)
-    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=wino)
+        conv(f"{name}.c1 3x3 {cin}->{cout} L{l}", npx(l), cin, cout, 9, wino=wino, level=l)
+    conv(f"{name}.c2 3x3 {cout}->{cout} L{l}", npx(l), cout, cout, 9, wino=wino, level=l)
     if cin != cout and not first and not res_first:
         conv(f"{name}.res 1x1 {cin}->{cout} L{l}", npx(l), cin, cout, 1)
 
@@ -91,8 +108,9 @@ for i, r in enumerate(rows):
     dur[i % n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 print(f"{evals} evaluations x {n} conv launches")
 tot_t = tot_f = 0.0
-print("[W] = Winograd F(2x2,3x3): GFLOP is what the MFMA units execute (direct count / 2.25); time is the GEMM launch only\n"
-      "(output transform included where it is fused into the kernel, input transform never)")
+print("[W] / [W24] / [W44] = Winograd F(2x2,3x3) / F(2x4,3x3) / F(4x4,3x3): GFLOP is what the MFMA units execute (2*M*N*K over the launch's\n"
+      "whole tiles: 4 / 3 / 2.25 multiplications per pixel instead of 9), fp32-equivalent (the f16x3 kernels execute three fp16 products per\n"
+      "count); time is the GEMM launch only (input / output transforms are their own kernels)")
 print(f"{'launch':48s} {'GFLOP':>8s} {'us':>8s} {'TF/s':>7s} {'share':>6s}")
 total_time = sum(sum(v) / len(v) for v in dur.values())
 for i, (name, fl, px, cin, cout, taps) in enumerate(seq):

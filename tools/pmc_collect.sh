@@ -1,7 +1,7 @@
 #!/bin/bash
 # Counter evidence for profiles/: separate rocprofv3 --pmc passes (never combined with trace domains other than --kernel-trace)
 # over one short bench.py sampling call, then tools/pmc_summary.py joins them per kernel instantiation and per U-Net launch.
-# usage (GPU box, repo root): tools/pmc_collect.sh <tag> [bench args]
+# usage (GPU box, repo root): [PMC_BENCH_ARGS='--batch 8'] tools/pmc_collect.sh <tag>
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -9,7 +9,7 @@ out=gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
 pass() {   # name, counters...
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -o p -- python3 bench.py --steps 1 --warmup 0 --diffusion-steps 4 --no-cpu-baseline --no-anchor > "$out/$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -o p -- python3 bench.py --steps 1 --warmup 0 --diffusion-steps 4 --no-cpu-baseline --no-anchor ${PMC_BENCH_ARGS:-} > "$out/$name.log" 2>&1
   f=$(find "$out/$name" -name '*counter_collection.csv' | head -1)
   if [ -z "$f" ]; then echo "pass $name produced no counters"; tail -3 "$out/$name.log"; return 1; fi
   mv "$f" "$out/$name.csv"; rm -rf "$out/$name"

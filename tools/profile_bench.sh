@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o t -- python3 b
 trace=$(find "$out" -name '*kernel_trace.csv' | head -1)
 stats=$(find "$out" -name '*kernel_stats.csv' | head -1)
 if [ -z "$trace" ] || [ -z "$stats" ]; then echo "no trace produced"; tail -5 "$out/bench.log"; exit 1; fi
-python3 tools/analyze_trace.py "$trace" > "$out/conv_per_launch.txt" || true
+python3 tools/analyze_trace.py "$trace" ${AT_ARGS:-} > "$out/conv_per_launch.txt" || true
 cp "$stats" "$out/kernel_stats.csv"
 find "$out" -name '*kernel_trace.csv' -delete
 tail -1 "$out/conv_per_launch.txt"
