@@ -17,7 +17,7 @@ d, out = sys.argv[1], sys.argv[2]
 
 
 def short(name):
-    n = name.replace("void ", "").replace("us::", "")
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("us::", "")
     return n.split("(")[0]
 
 
