@@ -1038,7 +1038,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // slower.  US_TN64=0 switches it off; the margin (percent) covers the thinner MFMA : LDS-read ratio.
         static int tn64 = -1;
         if (tn64 < 0) { const char* e = getenv("US_TN64"); tn64 = e ? atoi(e) : 25; }
-        if (tn64 > 0 && a.Cout % 64 == 0 && a.Cin >= 1024) {      // (K = 256 ... 512: twice the prologues and epilogues per unit of work cost more than the rounds saved: measured 34 -> 38 us, 102 -> 120 us)
+        if (tn64 > 0 && a.Cout % 64 == 0 && a.Cin >= 1024 && a.Hs * a.Ws > 128) {      // (K = 256 ... 512: twice the prologues and epilogues per unit of work cost more than the rounds saved: measured 34 -> 38 us, 102 -> 120 us)
           const long long per64 = (long long)((a.Hs * a.Ws + 255) / 256) * ((a.Cout + 63) / 64) * a.B;
           const long long cost64 = ((per64 + 255) / 256) * 128;
           // against the 256 x 128 form (the 128-row one measured no better than it wherever the model preferred it)
