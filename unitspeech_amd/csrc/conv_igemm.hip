@@ -1036,6 +1036,13 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // block: 12 instead of 24 MFMAs per chunk against the same A fragments).  B = 1 level-3 launch, 768 of them: three rounds of half
         // work instead of two of full -- measured 94.5 -> 89.5 us, a third of what the model promises: the half-width kernel runs its work ~15 %
         // slower.  US_TN64=0 switches it off; the margin (percent) covers the thinner MFMA : LDS-read ratio.
+        // short K (a level-1 / level-2 frequency of the 4-wide forms is 4 ... 16 chunks): the eight-wave kernel is one workgroup per CU and cannot
+        // hide a workgroup's prologue and epilogue behind another's loop; the 128-row kernel has two per CU.  K <= 512: B = 1 +0.6 %, B = 8
+        // +1.3 % (3,792 -> 3,841 frames/s); 64-row tiles no better.  US_WINO_TM_SHORTK = rows where K <= US_WINO_SHORTK (0: the model above).
+        static int tm_short = -1, k_short = -1;
+        if (tm_short < 0) { const char* e = getenv("US_WINO_TM_SHORTK"); tm_short = e ? atoi(e) : 128; }
+        if (k_short < 0) { const char* e = getenv("US_WINO_SHORTK"); k_short = e ? atoi(e) : 512; }
+        if (tm_short > 0 && a.Cin <= k_short) tm = tm_short;
         static int tn64 = -1;
         if (tn64 < 0) { const char* e = getenv("US_TN64"); tn64 = e ? atoi(e) : 25; }
         if (tn64 > 0 && a.Cout % 64 == 0 && a.Cin >= 1024 && a.Hs * a.Ws > 128) {      // (K = 256 ... 512: twice the prologues and epilogues per unit of work cost more than the rounds saved: measured 34 -> 38 us, 102 -> 120 us)
