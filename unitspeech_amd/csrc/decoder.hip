@@ -1337,7 +1337,11 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
       s->wino_f16 = s->shape[1] % 32 == 0;
       s->wino_dg_f16 = s->shape[0] % 32 == 0;
     }
-    if (ok && s->want_wino && s->wino_f16 && s->level >= 0 && s->level < 8 && wino4_form_ok(h->wino4_level_form[s->level]) && s->shape[0] % 8 == 0) {
+    // (not for K = Cin < US_WINO4_MIN_K (256): a frequency's GEMM is then four chunks long and the 36 of them run at 100 TFLOP/s; the level-1
+    // 128 -> 256 convolution took 91 + 25 + 50 us (GEMM, input, output transform) against 92 + 35 in the fused-output F(2x2) form)
+    static const int wino4_min_k = [] { const char* p = getenv("US_WINO4_MIN_K"); return p ? atoi(p) : 256; }();
+    if (ok && s->want_wino && s->wino_f16 && s->level >= 0 && s->level < 8 && wino4_form_ok(h->wino4_level_form[s->level]) && s->shape[0] % 8 == 0 &&
+        s->shape[1] >= wino4_min_k) {
       s->wino4_form = h->wino4_level_form[s->level];
       s->wino4.n = (size_t)wino4_freqs(s->wino4_form) * s->shape[0] * s->shape[1];
       ok = hipMalloc(reinterpret_cast<void**>(&s->wino4.p), s->wino4.n * sizeof(float)) == hipSuccess;
