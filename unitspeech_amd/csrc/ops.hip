@@ -27,12 +27,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // Mish (unitspeech/unitspeech.py:13-15): x*tanh(softplus(x)), softplus threshold 20.
 // tanh(log(1+w)) = ((1+w)^2-1)/((1+w)^2+1) = w(w+2)/(w(w+2)+2) with w = e^x: one exp, one divide, no cancellation.
 // v_exp_f32 / v_rcp_f32 forms (about 1 ulp each): the library expf and IEEE division made the GroupNorm+Mish pass
-// VALU-bound at 3 TB/s instead of HBM-bound.
+// VALU-bound at 3 TB/s instead of HBM-bound.  (Round 4: `__frcp_rn` turned out to BE an IEEE division on this compiler -- v_div_scale / v_rcp /
+// four fmas / v_div_fmas / v_div_fixup per value -- so the reciprocal is spelled __builtin_amdgcn_rcpf now.)
 __device__ __forceinline__ float mish_f(float x) {
   if (x > 20.f) return x;              // softplus(x) = x beyond the threshold and tanh(x > 20) == 1 in fp32
   float w = __expf(x);
   float u = w * (w + 2.f);
-  return x * (u * __frcp_rn(u + 2.f));
+  return x * (u * __builtin_amdgcn_rcpf(u + 2.f));
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -25,8 +25,8 @@ __device__ __forceinline__ float mish_grad(float z) {
   if (z > 20.f) return 1.f;
   float w = __expf(z);
   float u = w * (w + 2.f);
-  float th = u * __frcp_rn(u + 2.f);        // tanh(softplus(z))
-  float sg = w * __frcp_rn(1.f + w);        // sigmoid(z) = d softplus / dz
+  float th = u * __builtin_amdgcn_rcpf(u + 2.f);        // tanh(softplus(z)); v_rcp_f32 (__frcp_rn is an IEEE division sequence here)
+  float sg = w * __builtin_amdgcn_rcpf(1.f + w);        // sigmoid(z) = d softplus / dz
   return th + z * (1.f - th * th) * sg;
 }
 

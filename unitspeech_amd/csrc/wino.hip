@@ -115,7 +115,7 @@ __device__ __forceinline__ float gw_mish(float x) {              // == mish_f (o
   if (x > 20.f) return x;
   const float w = __expf(x);
   const float u = w * (w + 2.f);
-  return x * (u * __frcp_rn(u + 2.f));
+  return x * (u * __builtin_amdgcn_rcpf(u + 2.f));
 }
 
 template <bool SPLIT>
