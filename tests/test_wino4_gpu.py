@@ -114,6 +114,22 @@ def test_evaluation_and_50_step_loop_vs_reference_goldens(sd_np, monkeypatch, fo
     assert e32 <= 2e-6 and e64 <= 2e-6 and l32 <= 1e-3 and l64 <= 1e-3
 
 
+@pytest.mark.parametrize("T", [8, 40])
+def test_short_utterances_vs_oracle(sd_np, monkeypatch, T):
+    """T = 8: one column at level 3, two at level 2, four at level 1 -- a single, mostly empty tile column at every level of the 4-wide forms;
+    T = 40: 5 / 10 / 20 columns (partial last tiles at levels 3 and 2).  Full-size weights, a padded item, against the oracle."""
+    model = build(sd_np, monkeypatch, "0,44,44,24")
+    sd = O.to_torch(sd_np)
+    inp = G(synthetic_inputs(FULL, 2, T, seed=41, lengths=[T, max(T - 8, 4)]))
+    t = torch.tensor([0.8, 0.15])
+    with torch.no_grad():
+        out = model.estimator(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), t.to(DEV), inp["spk_emb"].to(DEV))
+    ref = O.estimator_forward(sd, inp["z"], inp["mask"], inp["cond"], t, inp["spk_emb"])
+    e = l1(out, ref)
+    print(f"\nT={T} evaluation: L1 vs oracle {e:.2e} (mean |ref| {ref.abs().mean():.3f})")
+    assert torch.isfinite(out).all() and e <= 2e-6
+
+
 def test_ragged_evaluation_and_batch_independence(sd_np, monkeypatch):
     """T = 136 (17 / 34 / 68 columns at levels 3 / 2 / 1: partial tile columns everywhere) with a padded and a fully padded item, against the
     oracle; and an item's result must not depend on what it is batched with, bit for bit (the tile of a Winograd-domain GEMM follows the
