@@ -68,12 +68,13 @@ def _debug_block(eng, kind, prefix, level, x_nchw, T, cout):
 # ---------------------------------------------------------------------------------------------------------------
 # range: the C ABI reports, never clamps
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("level,prefix,C_", [(0, "estimator.downs.0.1", 128), (1, "estimator.downs.1.1", 256)])
-def test_block_with_activations_beyond_the_fp16_range_is_reported_and_exact_on_the_fp32_handle(sd_np, level, prefix, C_):
-    """`Block` (conv3x3 -> GroupNorm -> Mish, :46-55) on an input of magnitude 1e5: level 0 runs the direct f16x3 convolution (split
-    inside the kernel), level 1 the Winograd form (V = B^T d B split by the input transform).  Default handle: status US_RANGE_ACT and
-    a non-finite output (the old behaviour was a finite, silently clamped one); exact-fp32 handle: status 0 and the oracle's values.
-    A well-scaled input leaves the status at 0 on both."""
+@pytest.mark.parametrize("level,prefix,C_,fine,beyond", [(0, "estimator.downs.0.1", 128, (1.0,), 1e5), (1, "estimator.downs.1.1", 256, (1.0, 2e4), 3e7)])
+def test_block_with_activations_beyond_the_fp16_range_is_reported_and_exact_on_the_fp32_handle(sd_np, level, prefix, C_, fine, beyond):
+    """`Block` (conv3x3 -> GroupNorm -> Mish, :46-55) on an input beyond the f16x3 operand range: level 0 runs the direct convolution (split
+    inside the kernel; |x| ~ 1e5), level 1 the Winograd F(4x4) form, whose input transform scales by 2^-5 (wino4.hip: V overflows near
+    |x| ~ 1e5 x 20 / 32, so 2e4 * N(0,1) -- values up to 9e4, beyond fp16 themselves -- stays on the fast path at full accuracy, and 3e7 does
+    not).  Default handle beyond the range: status US_RANGE_ACT and a non-finite output (round 2 returned a finite, silently clamped one);
+    exact-fp32 handle: status 0 and the oracle's values.  An in-range input leaves the status at 0 on both."""
     model = build(sd_np)
     T = 64
     H, W = FULL.n_feats >> level, T >> level
@@ -81,7 +82,7 @@ def test_block_with_activations_beyond_the_fp16_range_is_reported_and_exact_on_t
     x = torch.from_numpy(g.standard_normal((2, C_, H, W), dtype=np.float32))
     sd = O.to_torch(sd_np)
     ones = torch.ones(2, 1, 1, W)
-    for scale in (1.0, 1e5):
+    for scale in fine + (beyond,):
         xs = x * scale
         ref = O.block(sd, prefix + ".block1", xs, ones)
         eng = model._sync(torch.device(DEV))
@@ -92,8 +93,8 @@ def test_block_with_activations_beyond_the_fp16_range_is_reported_and_exact_on_t
         print(f"\nlevel {level}, |x| ~ {scale:g}: f16x3 status {st}, exact status {st_x}, exact L1 vs oracle {e_x:.2e}"
               + (f", f16x3 L1 {l1(got, ref):.2e}" if st == 0 else f", f16x3 finite share {torch.isfinite(got).float().mean().item():.3f}"))
         assert st_x == 0 and e_x <= 2e-6 * max(1.0, ref.abs().mean().item())
-        if scale == 1.0:
-            assert st == 0 and l1(got, ref) <= 2e-6
+        if scale in fine:
+            assert st == 0 and l1(got, ref) <= 2e-6 * max(1.0, ref.abs().mean().item())
         else:
             assert st & _lib.US_RANGE_ACT
             assert not torch.isfinite(got).all()             # loud: an overflow is an infinity, not 65504

@@ -46,6 +46,14 @@ __device__ __forceinline__ void axpy(f32x4& acc, float c, const f32x4& x, bool& 
   else acc += x * c;
 }
 
+// V = B^T d B carries up to (0.879 + 2.64 + 1)^2 = 20x the activation's magnitude for F(4x4) (F(2x2): 4x), which would move the fp16 range of
+// the two-plane operand from 65,504 / 4 to 65,504 / 20 of activation.  The transforms are linear, so the INPUT is scaled by 2^-5 (exact; folded
+// into the mask and time-embedding factors of the GroupNorm form, one multiply per loaded value otherwise) and the output transform multiplies Y
+// by 2^5 inside the bias add (an fma instead of an add): V overflows at |activation| ~ 100,000 now, beyond the direct convolutions' own 65,504.
+// Powers of two: every product and sum is the unscaled one times 2^-5 bit for bit (down to values of 2e-3, where hi becomes an fp16 subnormal and
+// the lo plane carries the difference at its 1.5e-11 floor).
+constexpr float kVScale = 0x1p-5f, kVUnscale = 0x1p+5f;
+
 // 1-D input transform t = B^T d along one axis.  The points are symmetric (+-a, +-b), so rows 1 / 2 and 3 / 4 of B^T are an even part plus /
 // minus an odd part: 18 multiply-adds for the six outputs instead of 22.  Coefficients come from the generated table (wino4_coef.h).
 template <int M> struct Bt;
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       sc = ga * rstd;
       sh = be - sc * meanf;
       te = g.temb ? *reinterpret_cast<const f32x4*>(g.temb + (long long)b * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      te *= kVScale;            // (mish * m + te) * m * 2^-5 == (mish * (m * 2^-5) + te * 2^-5) * m
     }
     // byte offsets per row / column; an invalid one has bit 31 set, so the sum is beyond the descriptor's range and the load returns zeros
     unsigned coff[NW];
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       const int ix = MW * tx - 1 + q;
       const bool ok = (unsigned)ix < (unsigned)W;
       coff[q] = ok ? ((unsigned)ix * (unsigned)x_ld + (unsigned)c) * 4u : 0x80000000u;      // (OR-ed below: two invalid flags must not carry out)
-      if (GN) cm[q] = ok ? mb[ix * g.mask_step] : 0.f;
+      if (GN) cm[q] = ok ? mb[ix * g.mask_step] : 0.f;      // (the frame mask, 0 / 1)
     }
     // along W first: tr[r][j] = sum_q BT_w[j][q] d[r][q]
     f32x4 tr[NH][NW];
@@ -147,8 +156,10 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
             const float w = __expf(z);
             const float u = w * (w + 2.f);
             const float mi = z > 20.f ? z : z * (u * __builtin_amdgcn_rcpf(u + 2.f));
-            v[k] = (mi * m + te[k]) * m;
+            v[k] = (mi * (m * kVScale) + te[k]) * m;
           }
+        } else {
+          v *= kVScale;
         }
         d[q] = v;
       }
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       for (int q = 0; q < MW; ++q) {
         const int oy = MH * ty + r, ox = MW * tx + q;
         if (oy < H && ox < W) {
-          const f32x4 v = y[r][q] + bv;
+          const f32x4 v = y[r][q] * kVUnscale + bv;       // (V was formed from the input times 2^-5: kVScale)
           *reinterpret_cast<f32x4*>(ob + ((long long)oy * W + ox) * out_ld) = v;
           if (stats) {
 #pragma unroll
