@@ -530,7 +530,8 @@ hipError_t wino_conv(EvalCtx& e, const float* in, int in_ld, const float* U, int
                      const WinoEpi& ep, const WinoGnArgs* gn = nullptr, bool f16 = false, int form4 = 0, const float* U4 = nullptr) {
   const int H = e.h->cfg.n_feats >> level, W = e.T >> level;
   Buffers& b = *e.b;
-  if (form4 && U4 && e.infer && !ep.add && !ep.mask_out && !(gn && gn->h_out) && (!gn || in_ld == K)) {
+  if (form4 && U4 && e.infer && !ep.add && !ep.mask_out && !(gn && gn->h_out) && (!gn || in_ld == K) &&
+      (long long)H * W * in_ld * 4 < (1LL << 31) && (long long)H * W * K < (1LL << 30)) {       // (launch_wino4_input's 32-bit offsets; else F(2x2))
     // F(4x4,3x3) / F(2x4,3x3): input transform (+ block1's GroupNorm), one GEMM over all items per frequency, output transform
     int t4h, t4w;
     wino4_tiles(form4, H, W, &t4h, &t4w);

@@ -364,6 +364,8 @@ void wino4_tiles(int form, int H, int W, int* th, int* tw) {
 
 hipError_t launch_wino4_input(int form, const float* x, int x_ld, float* V, int B, int H, int W, int C, const WinoGnArgs* gn, hipStream_t s) {
   if (!wino4_form_ok(form) || C % 8 != 0 || x_ld % 4 != 0 || B > 65535) return hipErrorInvalidValue;
+  // 32-bit byte offsets inside one item (buffer descriptor) and 32-bit element offsets inside one (frequency, item) plane of V
+  if ((long long)H * W * x_ld * 4 >= (1LL << 31) || (long long)H * W * C >= (1LL << 30)) return hipErrorInvalidValue;
   WinoGnArgs g{};
   if (gn) {
     g = *gn;
