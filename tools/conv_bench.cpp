@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <array>
+#include <algorithm>
 #include "../unitspeech_amd/csrc/kernels.h"
 using namespace us;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -221,7 +223,8 @@ int main(int argc, char** argv) {
                     {"G1 gemm 256->256", 16, 60, 256, 256, 256, 1, 1}, {"G1 gemm 512->128", 16, 60, 256, 512, 128, 1, 1},
                     {"G2 gemm 512->512", 16, 30, 128, 512, 512, 1, 1}, {"G2 gemm 1024->256", 16, 30, 128, 1024, 256, 1, 1},
                     {"G3 gemm 1024->1024", 16, 15, 64, 1024, 1024, 1, 1}, {"G3 gemm 2048->512", 16, 15, 64, 2048, 512, 1, 1},
-                    {"G3 gemm 512->512", 16, 15, 64, 512, 512, 1, 1}, {"G0 gemm 128->128", 16, 120, 512, 128, 128, 1, 1},
+                    {"G3 gemm 512->512", 16, 15, 64, 512, 512, 1, 1},
+                    {"H3 gemm 1024->1024", 24, 15, 32, 1024, 1024, 1, 1}, {"H2 gemm 512->512", 36, 15, 64, 512, 512, 1, 1}, {"G0 gemm 128->128", 16, 120, 512, 128, 128, 1, 1},
                     // wino = 2: output transform fused (B = items, H x W = tile grid, output 2H x 2W)
                     {"F0 fused 128->128", 3, 40, 512, 128, 128, 1, 2}, {"F1 fused 256->256", 3, 20, 256, 256, 256, 1, 2},
                     {"F1 fused 512->256", 3, 20, 256, 512, 256, 1, 2}, {"F2 fused 512->512 B24", 24, 10, 128, 512, 512, 1, 2},
@@ -232,7 +235,7 @@ int main(int argc, char** argv) {
   for (auto& sh : shapes) {
     if (getenv("CB_ONLY") && !strstr(sh.name, getenv("CB_ONLY"))) continue;
     size_t n_in = (size_t)sh.B * sh.H * sh.W * sh.Cin * (sh.wino == 2 ? 16 : 1), n_out = (size_t)sh.B * sh.H * sh.W * sh.Cout * (sh.wino == 2 ? 4 : 1);
-    size_t n_w = (size_t)sh.taps * sh.Cin * sh.Cout * (sh.wino ? 16 : 1);
+    size_t n_w = (size_t)sh.taps * sh.Cin * sh.Cout * (sh.wino == 1 ? sh.B / std::max(sh.B / 16, 1) : (sh.wino ? 16 : 1));
     float *in, *out, *w, *bias;
     CK(hipMalloc(&in, n_in * 4)); CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&w, n_w * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
     CK(launch_fill_normal(in, n_in, 1, 1, 0)); CK(launch_fill_normal(w, n_w, 1, 2, 0)); CK(launch_fill_normal(bias, sh.Cout, 1, 3, 0));
@@ -245,7 +248,8 @@ int main(int argc, char** argv) {
     const int n_ab = getenv("CB_AB") ? 2 : 1;           // CB_AB=<bit>: every case also with that debug bit set, back to back
     const int ab_bit = getenv("CB_AB") ? atoi(getenv("CB_AB")) : 0;
     for (int ab = 0; ab < n_ab; ++ab)
-    for (int tm : {256, 128, 64}) {
+    for (int tm : {0, 256, 128, 64}) {
+      if (tm == 0 && !(getenv("CB_TM") && atoi(getenv("CB_TM")) == 0)) continue;
       if (getenv("CB_TM") && atoi(getenv("CB_TM")) != tm) continue;
       if (tm == 256 && !(f16 && sh.wino != 2)) continue;
       const int debug = debug_arg | ((ab != 0) != (getenv("CB_AB_FIRST") != nullptr) ? ab_bit : 0);
@@ -263,7 +267,7 @@ int main(int argc, char** argv) {
       if (sh.wino == 2) { a.wt_bstride = (long long)sh.Cin * sh.Cout; a.wino_out = 1; a.ostep = 2; a.Hout = 2 * sh.H; a.Wout = 2 * sh.W; a.splitk_ws = nullptr; }
       if (sh.taps == 9) { for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) a.set_tap(ky * 3 + kx, ky - 1, kx - 1, ky * 3 + kx); }
       else a.set_tap(0, 0, 0, 0);
-#ifdef US_STAMP
+#if defined(US_STAMP) || defined(US_LIFE)
       static unsigned long long* stamps = nullptr;
       const size_t n_st = (size_t)1 << 22;
       if (!stamps) CK(hipMalloc(&stamps, n_st * 8));
@@ -272,6 +276,35 @@ int main(int argc, char** argv) {
 #endif
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       for (int i = 0; i < 3; ++i) CK(launch_conv_igemm(a, 0));
+#ifdef US_LIFE
+      {
+        // one more launch on a clean buffer: per workgroup (wave 0) entry / loop start / loop end / exit on the 100 MHz clock
+        CK(hipDeviceSynchronize());
+        CK(hipMemset(stamps, 0, n_st * 8));
+        CK(launch_conv_igemm(a, 0));
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hst(n_st);
+        CK(hipMemcpy(hst.data(), stamps, n_st * 8, hipMemcpyDeviceToHost));
+        std::vector<std::array<double, 4>> wg;
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i + 3 < n_st; i += 4) if (hst[i + 3]) t0 = std::min(t0, hst[i]);
+        for (size_t i = 0; i + 3 < n_st; i += 4) if (hst[i + 3]) wg.push_back({(hst[i] - t0) * 0.01, (hst[i + 1] - t0) * 0.01, (hst[i + 2] - t0) * 0.01, (hst[i + 3] - t0) * 0.01});
+        if (!wg.empty()) {
+          std::sort(wg.begin(), wg.end());
+          double pro = 0, loop = 0, epi = 0, last = 0;
+          for (auto& w : wg) { pro += w[1] - w[0]; loop += w[2] - w[1]; epi += w[3] - w[2]; last = std::max(last, w[3]); }
+          const double n = (double)wg.size();
+          printf("   life over %zu waves (us): prologue %.2f, loop %.2f, epilogue+stores %.2f; last exit at %.1f\n", wg.size(), pro / n, loop / n, epi / n, last);
+          printf("   entry times (us), deciles:");
+          for (int d = 0; d <= 10; ++d) printf(" %.1f", wg[std::min(wg.size() - 1, wg.size() * d / 10)][0]);
+          printf("\n   exit times (us), deciles:");
+          std::vector<double> ex; for (auto& w : wg) ex.push_back(w[3]);
+          std::sort(ex.begin(), ex.end());
+          for (int d = 0; d <= 10; ++d) printf(" %.1f", ex[std::min(ex.size() - 1, ex.size() * d / 10)]);
+          printf("\n");
+        }
+      }
+#endif
 #ifdef US_STAMP
       {
         CK(hipDeviceSynchronize());

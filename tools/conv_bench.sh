@@ -11,6 +11,13 @@ if [ "$1" = f16 ]; then
   CB_ONLY="${2:-G}" /tmp/conv_bench 9
   exit 0
 fi
+if [ "$1" = life ]; then
+  # workgroup lifetimes of the production tile choice (100 MHz stamps; -DUS_LIFE): tools/conv_bench.sh life [shape filter]
+  # (US_LIFE_DRAIN: the exit stamp waits for the wave's stores; without it the wave ends with its stores in flight, as in production)
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DUS_LIFE ${LIFE_FLAGS:-} tools/conv_bench.cpp unitspeech_amd/csrc/conv_igemm.hip unitspeech_amd/csrc/ops.hip -o /tmp/cb_life
+  for tm in ${LIFE_TMS:-0 256 128}; do echo "== CB_TM=$tm"; CB_ONLY="${2:-H3}" CB_F16=1 CB_TM=$tm /tmp/cb_life 9 | grep "TFLOP\|life\|times"; done
+  exit 0
+fi
 if [ "$1" = diag ]; then
   # where the three-buffer f16x3 GEMM spends a step: s_memtime stamps, then the timing ablations (results of the
   # ablated builds are wrong by construction): tools/conv_bench.sh diag [shape filter]

@@ -96,6 +96,11 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef US_LIFE      // diagnostic build (tools/conv_bench life): 100 MHz real-time stamps at a workgroup's entry, loop start, loop end and exit
+  unsigned long long life_t[5];
+#define US_LIFE_AT(i) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(life_t[i])::"memory")
+  US_LIFE_AT(0);
+#endif
   const int l32 = lane & 31, hh = lane >> 5;
   // Workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest, then z), each XCD with its own 4 MB L2.
   // Winograd-domain GEMMs (xcd_z: blockIdx.z = frequency, every frequency its own A and B): XCD k takes the k-th contiguous
@@ -487,6 +492,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
     }
   };
 
+#ifdef US_LIFE
+  US_LIFE_AT(1);
+#endif
   if (NSTG == 3) {
     // static priority for the second-dispatched half of an 8-wave workgroup (the arbitration loser of every segment); experiment bit
     if (NW == 8 && (a.debug & 512) && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -638,6 +646,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   if (WINO) fold(15);
 #endif
   }   // NSTG == 2
+#ifdef US_LIFE
+  US_LIFE_AT(2);
+#endif
   if (ASPLIT) range_report(a.range_flag, amax >= kF16Over, kRangeAct);
   if (!WINO) {
 #pragma unroll
@@ -864,6 +875,17 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
+#ifdef US_LIFE
+  US_LIFE_AT(4);                                         // every store issued
+#ifdef US_LIFE_DRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores have left the wave)
+#endif
+  US_LIFE_AT(3);
+  if (a.stamp_out && lane == 0) {
+    unsigned long long* o = a.stamp_out + ((blockIdx.x + gridDim.x * blockIdx.z) * NW + wave) * 4;
+    o[0] = life_t[0]; o[1] = life_t[1]; o[2] = life_t[2]; o[3] = life_t[3];
+  }
+#endif
 }
 
 // Second half of a split-K convolution: out = epilogue(sum_ks slab[ks]) with the same epilogue as the single-pass kernel.

@@ -137,6 +137,7 @@ struct us_decoder {
   int attn_wtotal_max_c = 128;       // US_ATTN_WTOTAL_MAXC (<= kWtotalMaxC)
   bool fuse_final = true;    // US_FUSE_FINAL=0: the final Block's GroupNorm + Mish as its own launch before the 1x1 projection
   bool wino_narrow = false; // US_WINO_NARROW=1: Winograd also for convolutions with cout <= dim below level 0 (add_resnet)
+  int wino_max_level = 99;  // US_WINO_MAX_LEVEL (experiment): levels beyond it run direct
   int wino_min_level = 1;   // ResnetBlock 3x3 convs at U-Net levels >= this run as Winograd F(2x2,3x3); US_WINO_MIN_LEVEL, 99 = off.  Level 0
                             // runs direct since the f16x3 kernels: at 80 x T the 4x-expanded V costs more than 2.25x fewer MFMA FLOPs save
   // F(4x4,3x3) / F(2x4,3x3) Winograd in inference, per U-Net level: 0 = F(2x2) (wino.hip), 44, 24 (wino4.hip); US_WINO4="l0,l1,l2,l3"
@@ -251,7 +252,7 @@ struct us_decoder {
     // level, 512 -> 128 and 128 -> 128 at 40 x T/2).  There the GEMMs have a single column tile, so nothing amortises the 4x-expanded V
     // (503 MB written and read for the 512-channel input at B' = 3) and the direct form is faster: measured 341 -> ~260 us and
     // 95 -> ~75 us per convolution, transform included (US_WINO_NARROW=1 brings the Winograd form back).
-    if (level >= wino_min_level && (cout > cfg.dim || wino_narrow)) {
+    if (level >= wino_min_level && level <= wino_max_level && (cout > cfg.dim || wino_narrow)) {
       if (!r.first) r.c1.w->want_wino = true;
       r.c2.w->want_wino = true;
     }
@@ -1251,6 +1252,7 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   hipError_t e = conv_igemm_init();
   if (e != hipSuccess) { g_last_error = std::string("conv_igemm_init: ") + hipGetErrorString(e); return US_EHIP; }
   if (const char* wl = getenv("US_WINO_MIN_LEVEL")) h->wino_min_level = atoi(wl);
+  if (const char* wl = getenv("US_WINO_MAX_LEVEL")) h->wino_max_level = atoi(wl);
   if (const char* ws = getenv("US_WINO_SPLITK")) h->wino_splitk = atoi(ws) != 0;
   {
     // per-level 4-wide Winograd form of the inference path (wino4.hip), "l0,l1,l2,l3": 0 = F(2x2,3x3), 44 = F(4x4,3x3), 24 = F(2x4,3x3)

@@ -127,7 +127,7 @@ struct ConvArgs {
   int* ksplit_out;       // ... is returned here (host pointer; 1 = `out` was written as usual)
   float* out2;           // optional second output, pixel-indexed like out (ld out2_ld): acc + bias BEFORE alpha / add / mask.  Training keeps
   int out2_ld;           // the Rezero branch's fn(x) this way: the gain's gradient is sum(grad_out * fn(x)) (unitspeech/unitspeech.py:36-43)
-#ifdef US_STAMP
+#if defined(US_STAMP) || defined(US_LIFE)
   unsigned long long* stamp_out;   // diagnostic build only: per (workgroup, wave) {cycles at the vmcnt wait, at the barrier, in the body, steps}
 #endif
   int debug;             // timing ablations for tools/conv_bench (0 in production): 1 = no DMA after the prologue,
