@@ -19,9 +19,11 @@ qs = collections.defaultdict(list)
 for s, e, n, q, g, w in seg: qs[q].append((s, e, n))
 for q, l in qs.items():
     print(f"queue {q}: {len(l)} launches busy {sum(e-s for s,e,_ in l)/1e6:.2f} ms span {(l[0][0]-t0)/1e6:.2f}..{(l[-1][1]-t0)/1e6:.2f}")
+import os
+pat = os.environ.get("PT_KERNELS", "wgrad_f16,wgrad_lds").split(",")
 for s, e, n, q, g, w in seg:
-    if "wgrad_f16" in n or "wgrad_lds" in n:
-        print(f"  {(s-t0)/1e3:9.1f} q{q} {(e-s)/1e3:8.1f} us grid {g}")
+    if any(p in n for p in pat):
+        print(f"  {(s-t0)/1e3:9.1f} q{q} {(e-s)/1e3:8.1f} us  {n.replace('us::','')[:60]}")
 PY
 find "$out" -name '*kernel_trace.csv' -delete
 tail -1 "$out/bench.log" | cut -c1-200

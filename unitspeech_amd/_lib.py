@@ -103,6 +103,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         if _lib is not None:
             return _lib
         path = _build.LIB
+        alt = os.environ.get("UNITSPEECH_AMD_LIB")          # experiments only: another build of the same ABI (A/B runs on one GPU box)
+        if alt:
+            if not os.path.exists(alt):
+                raise RuntimeError(f"UNITSPEECH_AMD_LIB={alt} does not exist")
+            path, build_if_missing = alt, False
         if build_if_missing:
             try:
                 path = _build.build_library(force=os.environ.get("UNITSPEECH_AMD_REBUILD") == "1")

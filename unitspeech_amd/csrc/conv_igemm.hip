@@ -711,7 +711,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
   // wave instruction, 4x fewer memory instructions than the native layout (the epilogue was half the time of the K=128
   // 1x1 convolutions and 11 % of the level-0 3x3s).
   __syncthreads();                                   // every wave is done with the operand buffers
-  if constexpr (!WINO && MB == 1 && NB == 2) {
+  if constexpr (!WINO && (MB == 1 || MB == 2) && NB == 2) {
     if (a.attn_part_ctx && n0 >= a.attn_q_cols) {
       // to_qkv column tiles 1 / 2: this wave's two 32-column blocks are k_h and v_h of head h for 32 of the tile's 64 rows
       // (qkv_src_row).  Linear attention (unitspeech/unitspeech.py:91-92): k = softmax over ALL n positions, ctx = k v^T; here the
@@ -722,13 +722,17 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       float* xm = smem;                  // [wn][wm][32]  column maxima of each wave
       float* xs = smem + 128;            // [wn][32]      column sums of wave wm = 1
       float* xc = smem + 256;            // [wn][32][32]  ctx of wave wm = 1
-      const int mrow0 = m0 + wm * 32 + 4 * hh;
+      // (MB = 2: the 128-row tile, ConvArgs::attn_rows = 128 -- each wave holds 64 rows of k_h | v_h as two 32-row blocks; one chunk of
+      // partials per 128 rows: half the hand-offs, half the partials to merge)
+      const int mrow0 = m0 + wm * WM + 4 * hh;
       float kmax = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = mrow0 + (r & 3) + 8 * (r >> 2) < Ms;
-        kmax = fmaxf(kmax, ok ? acc[0][0][r] : -INFINITY);
-      }
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = mrow0 + mb * 32 + (r & 3) + 8 * (r >> 2) < Ms;
+          kmax = fmaxf(kmax, ok ? acc[mb][0][r] : -INFINITY);
+        }
       kmax = fmaxf(kmax, __shfl_xor(kmax, 32));
       if (hh == 0) xm[(wn * 2 + wm) * 32 + l32] = kmax;
       __syncthreads();
@@ -738,13 +742,15 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_igemm_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
       float ssum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = mrow0 + (r & 3) + 8 * (r >> 2) < Ms;
-        const float p = ok ? expf(acc[0][0][r] - mcol) : 0.f;
-        const float v = ok ? acc[0][1][r] : 0.f;
-        ssum += p;
-        ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v, ctx, 0, 0, 0);
-      }
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = mrow0 + mb * 32 + (r & 3) + 8 * (r >> 2) < Ms;
+          const float p = ok ? expf(acc[mb][0][r] - mcol) : 0.f;
+          const float v = ok ? acc[mb][1][r] : 0.f;
+          ssum += p;
+          ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v, ctx, 0, 0, 0);
+        }
       ssum += __shfl_xor(ssum, 32);
       if (wm == 1) {
         if (hh == 0) xs[wn * 32 + l32] = ssum;
@@ -1100,9 +1106,10 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   if (a.attn_part_ctx) {
     // to_qkv with the attention reduction in the epilogue: three 128-column tiles, 64-row tiles (one chunk of partials each), one pass
     if (!((a.Cout == 3 * kHidden && a.attn_q_cols == kHidden) || (a.Cout == 2 * kHidden && a.attn_q_cols == 0)) || a.ntaps != 1 || a.istride != 1 || a.ostep != 1 || a.wino_out || a.nphase > 1 || a.bias || a.add || a.alpha ||
-        a.stats || a.f16 == 1 || !a.attn_part_m || !a.attn_part_s || a.attn_nchunks != (a.Hs * a.Ws + 63) / 64)
+        a.stats || a.f16 == 1 || !a.attn_part_m || !a.attn_part_s || (a.attn_rows != 0 && a.attn_rows != 64 && a.attn_rows != 128) ||
+        a.attn_nchunks != (a.Hs * a.Ws + (a.attn_rows ? a.attn_rows : 64) - 1) / (a.attn_rows ? a.attn_rows : 64))
       return hipErrorInvalidValue;
-    tm = 64;
+    tm = a.attn_rows ? a.attn_rows : 64;
     a.splitk_ws = nullptr;
   }
   if (a.nphase > 1) {

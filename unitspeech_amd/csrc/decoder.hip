@@ -135,6 +135,7 @@ struct us_decoder {
   // (measured at B = 1: level 0 only +0.9 %; level 0 and the 128-channel up level +0.6 %; levels 0-1 incl. the 256-channel one +0.0 %)
   int attn_wtotal_levels = 0x1;
   int attn_wtotal_max_c = 128;       // US_ATTN_WTOTAL_MAXC (<= kWtotalMaxC)
+  int attn_chunk_rows = 64;          // US_ATTN_CHUNK: rows per chunk of the to_qkv epilogue's online-softmax partials (64 | 128 = its row tile)
   bool fuse_final = true;    // US_FUSE_FINAL=0: the final Block's GroupNorm + Mish as its own launch before the 1x1 projection
   bool wino_narrow = false; // US_WINO_NARROW=1: Winograd also for convolutions with cout <= dim below level 0 (add_resnet)
   int wino_max_level = 99;  // US_WINO_MAX_LEVEL (experiment): levels beyond it run direct
@@ -839,8 +840,9 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
     // out = x + g (W_total x + b_o), W_total[b] = W_out blockdiag(ctx[b]^T) W_q: a C x C projection of x per item instead of q = W_q x written
     // ([n][128]), read back and projected with K = 128 (a third less to_qkv work and 2 * n * 128 floats less traffic; worth it where C <= 256)
     const int H = e.h->cfg.n_feats >> l, W = e.T >> l;
-    const int nch64 = (n + 63) / 64;
+    const int nch64 = (n + e.h->attn_chunk_rows - 1) / e.h->attn_chunk_rows;
     ConvArgs a = base_args(e, at.qkv, in, in_ld, H, W, qkv, kHidden, H, W);
+    a.attn_rows = e.h->attn_chunk_rows;
     a.Cout = 2 * kHidden;
     a.wt_rows = 3 * kHidden;
     // rows kHidden.. of every K-chunk of the qkv_src_row-ordered pack (per head k_h | v_h)
@@ -866,9 +868,10 @@ hipError_t attention(EvalCtx& e, const AttnW& at, const float* in, int in_ld, fl
   if (e.h->attn_fuse && at.qkv.w->qkv_rows.p) {
     // to_qkv with the n-reduction in its epilogue: only q is written ([n][128]); chunks of 64 rows (ConvArgs::attn_part_ctx)
     const int H = e.h->cfg.n_feats >> l, W = e.T >> l;
-    const int nch64 = (n + 63) / 64;
+    const int nch64 = (n + e.h->attn_chunk_rows - 1) / e.h->attn_chunk_rows;
     q_ld = kHidden;
     ConvArgs a = base_args(e, at.qkv, in, in_ld, H, W, qkv, q_ld, H, W);
+    a.attn_rows = e.h->attn_chunk_rows;
     a.wt = at.qkv.w->qkv_rows.p;
     a.ntaps = 1;
     a.set_tap(0, 0, 0, 0);
@@ -1284,6 +1287,7 @@ int us_decoder_create_ex(us_handle* out, const us_config* cfg, unsigned flags) {
   if (const char* wf = getenv("US_ATTN_FUSE")) h->attn_fuse = atoi(wf) != 0;
   if (const char* ff = getenv("US_FUSE_FINAL")) h->fuse_final = atoi(ff) != 0;
   if (const char* aw = getenv("US_ATTN_WTOTAL")) h->attn_wtotal_levels = atoi(aw);
+  if (const char* ac = getenv("US_ATTN_CHUNK")) h->attn_chunk_rows = atoi(ac) == 128 ? 128 : 64;
   if (const char* aw = getenv("US_ATTN_WTOTAL_MAXC")) h->attn_wtotal_max_c = atoi(aw) > kWtotalMaxC ? kWtotalMaxC : atoi(aw);
   if (const char* ws = getenv("US_WGRAD_STREAM")) h->wgrad_side_streams = atoi(ws) < 0 ? 0 : (atoi(ws) > Tape::kSideMax ? Tape::kSideMax : atoi(ws));
   if (flags & US_CREATE_EXACT_FP32) h->f16x3 = false;

@@ -118,7 +118,8 @@ struct ConvArgs {
   float* attn_part_ctx;  // [B][attn_nchunks][4][32][32]; non-null selects the mode (single pass, 64-row tiles)
   float* attn_part_m;    // [B][attn_nchunks][128]
   float* attn_part_s;    // [B][attn_nchunks][128]
-  int attn_nchunks;      // ceil(Hs * Ws / 64)
+  int attn_nchunks;      // ceil(Hs * Ws / attn_rows)
+  int attn_rows;         // rows per chunk = rows per workgroup: 64 (0 means 64) or 128
   int attn_q_cols;       // kHidden: column tile 0 is q and is stored; 0: the launch computes k | v only (Cout = 2 * kHidden, nothing stored:
                          // the caller folds W_q into the output projection, launch_attn_wtotal)
   int wt_rows;           // rows per K-chunk of the packed weight when the launch uses only Cout of them (0: Cout)
@@ -306,6 +307,7 @@ struct WgradArgs {
   const float* gy_amax;  // device float: max |gy| over (at least) the pixels and channels this launch reads, taken by launch_wgrad_amax
                          // into a zeroed word; the f16x3 form derives its exact power-of-two scale of the gradient operand from it
   int overwrite;         // 1: gw holds garbage; legal only when every element has exactly one writer (launch_wgrad_single_writer)
+  int div_addr;          // f16x3 kernel: 1 = recompute every DMA row's coordinates by division in every stage (the form until round 4; US_WGRAD_DIV=1)
   unsigned long long dy_bits, dx_bits, wtap_bits;
   void set_tap(int i, int dy, int dx, int wtap) {
     dy_bits |= (unsigned long long)(dy + 8) << (4 * i);

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 constexpr int kWgKP16 = 16;
 
+template <bool CARRIED>
 __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];      // raw: 2 stages x (A [16][128] + B [16][128]) fp32; then the fragment image
   constexpr int RAW = 2 * kWgKP16 * 128;                           // floats per raw stage (both operands)
@@ -289,21 +290,53 @@ __global__ __launch_bounds__(256, 3) void wgrad_f16_kernel(WgradArgs a) {
 
   // DMA role as in wgrad_lds_kernel: instruction j of this wave covers stage rows wave*4 + 2j + (lane>>5), channels (lane&31)*4..+3
   const int lrow = lane >> 5, lch = (lane & 31) * 4;
+  // The coordinates of a lane's two rows advance by 16 pixels per stage.  Recomputing them from the pixel index (two divisions and six
+  // 32-bit multiplies per row: 36 quarter-rate integer instructions per stage, ~580 issue cycles beside 384 cycles of MFMA) was the largest
+  // VALU item of the loop; they are carried instead: position in the row, row, and the two byte offsets, moved by wave-uniform increments
+  // (one wrap per step at most: Ws >= 16; narrower grids keep the division form).
+  constexpr bool carried = CARRIED;      // (the launcher: Ws >= 16)
+  int s_pos[2];          // (row << 16) | position in the row
+  unsigned s_g[2], s_x[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int vm = m_lo + wave * 4 + 2 * j + lrow;
+    const int bi = vm / Ms, m = vm - bi * Ms;        // (bi = 0 outside vmode)
+    const int yy = m / a.Ws, xx = m - yy * a.Ws;
+    s_pos[j] = (yy << 16) | xx;
+    s_g[j] = (unsigned)bi * gy_item + ((unsigned)((a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * (unsigned)a.gy_ld + (unsigned)(co0 + lch)) * 4u;
+    // (wraps below zero where the tap leaves the image: used only where it does not)
+    s_x[j] = (unsigned)bi * x_item + ((unsigned)((yy * a.istride + dy) * a.Win + xx * a.istride + dx) * (unsigned)a.x_ld + (unsigned)(ci0 + lch)) * 4u;
+  }
+  const unsigned g_dx = (unsigned)(kWgKP16 * a.ostep * a.gy_ld) * 4u, x_dx = (unsigned)(kWgKP16 * a.istride * a.x_ld) * 4u;
+  const unsigned g_row = (unsigned)((a.ostep * a.Wout - a.Ws * a.ostep) * a.gy_ld) * 4u, x_row = (unsigned)((a.istride * a.Win - a.Ws * a.istride) * a.x_ld) * 4u;
+  const unsigned g_item = gy_item - (unsigned)(a.Hs * a.ostep * a.Wout * a.gy_ld) * 4u, x_itemd = x_item - (unsigned)(a.Hs * a.istride * a.Win * a.x_ld) * 4u;
   auto dma = [&](int stage_m0, int buf) {
     float* As = wsm + buf * RAW;
     float* Bs = As + kWgKP16 * 128;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = wave * 4 + 2 * j;
-      const int vm = stage_m0 + r + lrow;
       unsigned goff = gy_bytes, xoff = x_bytes;      // out of range: zeros
-      if (vm < m_hi) {
-        const int bi = vm / Ms, m = vm - bi * Ms;    // (bi = 0 outside vmode)
-        const int yy = m / a.Ws, xx = m - yy * a.Ws;
-        goff = (unsigned)bi * gy_item + ((unsigned)((a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * (unsigned)a.gy_ld + (unsigned)(co0 + lch)) * 4u;
-        const int iy = yy * a.istride + dy, ix = xx * a.istride + dx;
-        if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
-          xoff = (unsigned)bi * x_item + ((unsigned)(iy * a.Win + ix) * (unsigned)a.x_ld + (unsigned)(ci0 + lch)) * 4u;
+      if (carried) {
+        const int iy = __mul24(s_pos[j] >> 16, a.istride) + dy, ix = __mul24(s_pos[j] & 0xffff, a.istride) + dx;      // (full-rate 24-bit multiplies)
+        const bool pv = stage_m0 + r + lrow < m_hi;
+        goff = pv ? s_g[j] : gy_bytes;
+        xoff = (pv && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win) ? s_x[j] : x_bytes;
+        s_pos[j] += kWgKP16; s_g[j] += g_dx; s_x[j] += x_dx;
+        if ((s_pos[j] & 0xffff) >= a.Ws) {
+          s_pos[j] += 0x10000 - a.Ws; s_g[j] += g_row; s_x[j] += x_row;
+          if ((s_pos[j] >> 16) >= a.Hs) { s_pos[j] -= a.Hs << 16; s_g[j] += g_item; s_x[j] += x_itemd; }
+        }
+      } else {
+        const int vm = stage_m0 + r + lrow;
+        if (vm < m_hi) {
+          const int bi = vm / Ms, m = vm - bi * Ms;    // (bi = 0 outside vmode)
+          const int yy = m / a.Ws, xx = m - yy * a.Ws;
+          goff = (unsigned)bi * gy_item + ((unsigned)((a.oy0 + yy * a.ostep) * a.Wout + a.ox0 + xx * a.ostep) * (unsigned)a.gy_ld + (unsigned)(co0 + lch)) * 4u;
+          const int iy = yy * a.istride + dy, ix = xx * a.istride + dx;
+          if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
+            xoff = (unsigned)bi * x_item + ((unsigned)(iy * a.Win + ix) * (unsigned)a.x_ld + (unsigned)(ci0 + lch)) * 4u;
+        }
       }
       wg_blds16(rsrc_g, goff, As + r * 128);
       wg_blds16(rsrc_x, xoff, Bs + r * 128);
@@ -402,11 +435,21 @@ __global__ __launch_bounds__(256) void wgrad_amax_kernel(const float* __restrict
   const int C4 = C >> 2;
   const long long total = rows * C4;
   float mx = 0.f;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / C4;
-    const int c = (int)(i - r * C4) * 4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(g + r * ld + c);
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  // (at most 512 blocks, launch_wgrad_amax: four 16-byte loads in flight per thread, or a level-0 tensor of a pre-training batch is read at
+  // a fraction of the HBM rate)
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long iu = i + u * stride;
+      const long long il = iu < total ? iu : i;
+      const long long r = ld == C ? 0 : il / C4;           // (a dense tensor is one long row)
+      const long long e = ld == C ? il * 4 : r * ld + (il - r * C4) * 4;
+      v[u] = *reinterpret_cast<const f32x4*>(g + e);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -461,6 +504,9 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     if (use_f16 && !a.exact) {
       if (!a.gy_amax) return hipErrorInvalidValue;      // the f16x3 form needs the exact maximum of gy (launch_wgrad_amax)
       WgradArgs a2 = a;
+      static int div_addr = -1;      // US_WGRAD_DIV=1: the per-stage division form of the DMA addresses (A/B)
+      if (div_addr < 0) { const char* e = getenv("US_WGRAD_DIV"); div_addr = e ? atoi(e) : 0; }
+      a2.div_addr = div_addr;
       static int target_wgs = -1;
       if (target_wgs < 0) { const char* e = getenv("US_WGRAD_WGS"); target_wgs = e ? atoi(e) : 1536; }
       const long long V = (long long)a.B * Ms;
@@ -479,11 +525,14 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
       const int lds16 = (2 * 2 * kWgKP16 * 128 + 2 * 128 * 16) * (int)sizeof(float);
       static bool attr16_set = false;
       if (!attr16_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
         if (e != hipSuccess) return e;
         attr16_set = true;
       }
-      hipLaunchKernelGGL(wgrad_f16_kernel, g2, dim3(256), lds16, s, a2);
+      if (a2.Ws >= kWgKP16 && a2.Ws < 0x8000 && a2.Hs < 0x8000 && !a2.div_addr) hipLaunchKernelGGL(wgrad_f16_kernel<true>, g2, dim3(256), lds16, s, a2);
+      else hipLaunchKernelGGL(wgrad_f16_kernel<false>, g2, dim3(256), lds16, s, a2);
       return hipGetLastError();
     }
     hipLaunchKernelGGL(wgrad_lds_kernel, g2, dim3(256), lds, s, a);
@@ -702,16 +751,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   int w = (int)(p % a.W);
   const long long rpi = stride / C4;
   const int wstep = (int)(rpi % a.W);
-  for (; i < total; i += stride) {
-    if (!fixed_quad) {
-      p = i / C4;
-      w = (int)(p % a.W);
-      c = (int)(i - p * C4) * 4;
-      if (c != cur) load_quad(c);
-    }
-    const float m = mb[w * a.mask_step];
-    const f32x4 yv = *reinterpret_cast<const f32x4*>(yb + p * a.y_ld + c);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + p * a.g_ld + c);
+  auto element = [&](const f32x4& yv, const f32x4& gv, float m, long long pp) {
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -729,17 +769,49 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
         gy_max = fmaxf(gy_max, fabsf(o[k]));
       }
     }
-    if (PASS == 2) *reinterpret_cast<f32x4*>(ob + p * a.gy_ld + c) = o;
+    if (PASS == 2) *reinterpret_cast<f32x4*>(ob + pp * a.gy_ld + c) = o;
     if (PASS == 1 && ++since_flush == kGnFlush) {      // (one thread rarely gets this far: 4-10 elements per quad at training sizes)
       const int keep = cur;
       flush();
       cur = keep;
       since_flush = 0;
     }
-    if (fixed_quad) {
-      p += rpi;
-      w += wstep;
-      if (w >= a.W) w -= a.W;
+  };
+  if (fixed_quad) {
+    // The launch is capped at ~512 blocks (the atomics at a block's end, launch_gn_bwd), i.e. two per CU: with one pair of 16-byte loads
+    // in flight per thread the pass ran at 1-2 TB/s at a pre-training batch.  Four elements' loads are issued before the first is used.
+    constexpr int U = 4;
+    while (i < total) {
+      f32x4 yv[U], gv[U];
+      float mm[U];
+      long long pp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        pp[u] = p;
+        const bool ok = i + u * stride < total;
+        const long long pl = ok ? p : 0;
+        mm[u] = mb[(ok ? w : 0) * a.mask_step];
+        yv[u] = *reinterpret_cast<const f32x4*>(yb + pl * a.y_ld + c);
+        gv[u] = *reinterpret_cast<const f32x4*>(gb + pl * a.g_ld + c);
+        p += rpi;
+        w += wstep;
+        if (w >= a.W) w -= a.W;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i + u * stride < total) element(yv[u], gv[u], mm[u], pp[u]);
+      i += U * stride;
+    }
+  } else {
+    for (; i < total; i += stride) {
+      p = i / C4;
+      w = (int)(p % a.W);
+      c = (int)(i - p * C4) * 4;
+      if (c != cur) load_quad(c);
+      const float m = mb[w * a.mask_step];
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(yb + p * a.y_ld + c);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + p * a.g_ld + c);
+      element(yv, gv, m, p);
     }
   }
   flush();

@@ -52,11 +52,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   const long long per_item = (long long)th * tw * C4;
   const long long plane = (long long)B * th * tw * C;          // floats per frequency
   const float* xb = x + (long long)b * H * W * x_ld;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per_item; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    long long t = i / C4;
-    const int tx = (int)(t % tw);
-    const int ty = (int)(t / tw);
+  // (32-bit index arithmetic, per_item < 2^31 host-checked: the four 64-bit divisions per tile cost more than the transform)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)per_item; i += gridDim.x * 256u) {
+    const unsigned t = i / (unsigned)C4;
+    const int c = (int)(i - t * (unsigned)C4) * 4;
+    const int ty = (int)(t / (unsigned)tw);
+    const int tx = (int)(t - (unsigned)ty * (unsigned)tw);
     f32x4 d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 hipError_t launch_wino_input(const float* x, int x_ld, float* V, int B, int H, int W, int C, hipStream_t s, bool split) {
   if (C % 4 != 0 || x_ld % 4 != 0) return hipErrorInvalidValue;
   const long long per_item = (long long)((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  if (per_item >= (1LL << 31)) return hipErrorInvalidValue;
   int blocks = (int)((per_item + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
@@ -234,11 +236,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       }
     }
   };
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per_item; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    long long t = i / C4;
-    const int tx = (int)(t % tw);
-    const int ty = (int)(t / tw);
+  // (32-bit index arithmetic: per_item < 2^31, host-checked; the four 64-bit divisions per tile were a third of this kernel's instructions)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)per_item; i += gridDim.x * 256u) {
+    const unsigned t = i / (unsigned)C4;
+    const int c = (int)(i - t * (unsigned)C4) * 4;
+    const int ty = (int)(t / (unsigned)tw);
+    const int tx = (int)(t - (unsigned)ty * (unsigned)tw);
     const float* mb = M + (((long long)b * th + ty) * tw + tx) * C + c;
     f32x4 m[4][4];
 #pragma unroll
@@ -331,6 +334,7 @@ hipError_t launch_wino_output(const float* M, const float* bias, float* out, int
   if (extra) x = *extra;
   if (x.mask_bmod < 1) x.mask_bmod = 1;
   const long long per_item = (long long)((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  if (per_item >= (1LL << 31)) return hipErrorInvalidValue;
   int blocks = (int)((per_item + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;

@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       }
     }
   };
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per_item; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    const long long t = i / C4;
-    const int tx = (int)(t % tw);
-    const int ty = (int)(t / tw);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)per_item; i += gridDim.x * 256u) {      // (32-bit: per_item < 2^31, host-checked)
+    const unsigned t = i / (unsigned)C4;
+    const int c = (int)(i - t * (unsigned)C4) * 4;
+    const int ty = (int)(t / (unsigned)tw);
+    const int tx = (int)(t - (unsigned)ty * (unsigned)tw);
     const float* mb = M + (((long long)b * th + ty) * tw + tx) * C + c;
     f32x4 y[MH][MW];
 #pragma unroll
@@ -391,6 +391,7 @@ hipError_t launch_wino4_output(int form, const float* M, const float* bias, floa
   if (!wino4_form_ok(form) || C % 4 != 0 || out_ld % 4 != 0 || C % kGroups != 0 || B > 65535) return hipErrorInvalidValue;
   int th, tw;
   wino4_tiles(form, H, W, &th, &tw);
+  if ((long long)th * tw * (C / 4) >= (1LL << 31)) return hipErrorInvalidValue;      // (the kernel's 32-bit tile index)
   const dim3 grid(grid_for((long long)th * tw * (C / 4)), B);
   if (form == 44) hipLaunchKernelGGL((wino4_output_kernel<4, 4>), grid, dim3(256), 0, s, M, bias, out, out_ld, stats, B, H, W, C);
   else hipLaunchKernelGGL((wino4_output_kernel<2, 4>), grid, dim3(256), 0, s, M, bias, out, out_ld, stats, B, H, W, C);
