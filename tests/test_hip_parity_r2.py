@@ -172,6 +172,21 @@ def test_strong_attention_evaluation_vs_reference(golden, tag, cfg, Tn):
     assert e <= 2e-6 and e64 <= 2e-6
 
 
+def test_strong_attention_with_128_row_chunks(golden, monkeypatch):
+    """US_ATTN_CHUNK=128: to_qkv on 128-row tiles, one chunk of online-softmax partials per 128 rows (the two-block form of the
+    epilogue in conv_igemm.hip).  Measured slower and off by default; the path is held to the same bar as the default one, on the
+    attention-dominated weights, with ragged lengths (chunks that end inside a tile)."""
+    g = G(golden("estimator_full_attn"))
+    monkeypatch.setenv("US_ATTN_CHUNK", "128")
+    model = make_model(FULL, rezero_g=1.0, qkv_scale=1.0)          # the switch is read when the handle is created
+    inp = G(synthetic_inputs(FULL, 3, 64, seed=2, lengths=[int(v) for v in g["lengths"]]))
+    with torch.no_grad():
+        out = model.estimator(inp["z"].to(DEV), inp["mask"].to(DEV), inp["cond"].to(DEV), g["t"].to(DEV), inp["spk_emb"].to(DEV))
+    e, e64 = l1(out, g["out"]), l1(out, g["out_fp64"])
+    print(f"\n128-row attention chunks: L1 vs reference {e:.3e}, vs fp64 {e64:.3e}")
+    assert e <= 2e-6 and e64 <= 2e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # per-module outputs of the reference (tests/golden/blocks_tiny.npz) through us_debug_block
 # ---------------------------------------------------------------------------------------------------------------
