@@ -962,8 +962,101 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
   }
 }
 
+// The same on the matrix cores.  Per head the two products are 32 x 32 GEMMs over a block of 32 pixels,
+//   T^T[d][p] = sum_e gctx[d][e] v[p][e],   GV^T[e][p] = sum_d gctx[d][e] P[p][d],
+// with the pixel on the MFMA's column index: a lane owns one pixel (it loads the pixel's 32 k and 32 v values of the head as eight 16-byte
+// vectors each and feeds v / P as the B operand straight from those registers, element 2j + hh at step j), gctx is the A operand (16 + 16
+// registers per lane, loaded once per workgroup: wave = head), and the results come back with the pixel on the lane and 16 of the head's
+// channels in the registers -- four 16-byte stores per output and pixel.  v_mfma_f32_32x32x2_f32: exact fp32 products and sums, as the
+// shuffle form's fmas (another order).  The shuffle form spent 32 x (2 shuffles + 2 LDS reads + 2 fmas) per pixel and head: 1.1 ms for the
+// level-0 attention of a pre-training batch.
+__global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                               const float* __restrict__ gctx, const float* __restrict__ colM,
+                                                               const float* __restrict__ colS, int n, float* __restrict__ gqkv) {
+  __shared__ __attribute__((aligned(16))) float s_m[kHidden], s_is[kHidden], s_cc[kHidden];
+  const int b = blockIdx.y;
+  const float* gc = gctx + (long long)b * kHeads * kDimHead * kDimHead;
+  const float* cx = ctx + (long long)b * kHeads * kDimHead * kDimHead;
+  if (threadIdx.x < kHidden) {
+    const int hd = threadIdx.x;              // h * 32 + d
+    float acc = 0.f;
+    for (int e = 0; e < kDimHead; ++e) acc += cx[hd * kDimHead + e] * gc[hd * kDimHead + e];
+    s_cc[hd] = acc;
+    s_m[hd] = colM[(long long)b * kHidden + hd];
+    s_is[hd] = 1.f / colS[(long long)b * kHidden + hd];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int l32 = lane & 31, hh = lane >> 5;
+  const float* gh = gc + h * kDimHead * kDimHead;
+  float a1[16], a2[16];                      // A operands: gctx[d = l32][e = 2j + hh];  gctx[d = 2j + hh][e = l32]
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    a1[j] = gh[l32 * kDimHead + 2 * j + hh];
+    a2[j] = gh[(2 * j + hh) * kDimHead + l32];
+  }
+  const int nblk = (n + 31) / 32;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int p = blk * 32 + l32;
+    const bool pv = p < n;
+    const float* row = qkv + ((long long)b * n + (pv ? p : 0)) * (3 * kHidden) + h * kDimHead;
+    f32x4 kq[8], vq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      kq[i] = *reinterpret_cast<const f32x4*>(row + kHidden + 4 * i);
+      vq[i] = *reinterpret_cast<const f32x4*>(row + 2 * kHidden + 4 * i);
+    }
+    // P[d] = exp(k[d] - M[d]) / S[d] for the pixel's 32 channels of this head (the statistics: uniform LDS reads)
+    float P[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(s_m + h * kDimHead + 4 * i);
+      const f32x4 is4 = *reinterpret_cast<const f32x4*>(s_is + h * kDimHead + 4 * i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) P[4 * i + k] = pv ? expf(kq[i][k] - m4[k]) * is4[k] : 0.f;
+    }
+    f32x16 T, GV;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { T[r] = 0.f; GV[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float v0 = vq[j >> 1][(2 * j) & 3], v1 = vq[j >> 1][(2 * j + 1) & 3];
+      const float bv = pv ? (hh ? v1 : v0) : 0.f;
+      const float bp = hh ? P[2 * j + 1] : P[2 * j];
+      T = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv, T, 0, 0, 0);
+      GV = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], bp, GV, 0, 0, 0);
+    }
+    if (pv) {
+      float* orow = gqkv + ((long long)b * n + p) * (3 * kHidden) + h * kDimHead;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // registers 4g .. 4g + 3 hold rows 8g + 4hh + (0..3): channel d (of T^T) resp. e (of GV^T)
+        const int d0 = 8 * g + 4 * hh;
+        const f32x4 cc4 = *reinterpret_cast<const f32x4*>(s_cc + h * kDimHead + d0);
+        f32x4 gk4, gv4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float pd = hh ? P[8 * g + 4 + k] : P[8 * g + k];
+          gk4[k] = pd * (T[4 * g + k] - cc4[k]);
+          gv4[k] = GV[4 * g + k];
+        }
+        *reinterpret_cast<f32x4*>(orow + kHidden + d0) = gk4;
+        *reinterpret_cast<f32x4*>(orow + 2 * kHidden + d0) = gv4;
+      }
+    }
+  }
+}
+
 hipError_t launch_attn_bwd_kv(const float* qkv, const float* ctx, const float* gctx, const float* colM, const float* colS, int B,
                               int n, float* gqkv, hipStream_t s) {
+  static const bool mfma = [] { const char* e = getenv("US_ATTN_BWD_KV_MFMA"); return !e || atoi(e) != 0; }();
+  if (mfma) {
+    int bm = (n + 31) / 32;                  // 32-pixel blocks of an item; a workgroup's prologue (gctx, cc) wants several of them at a batch
+    const int cap = 1024 / B < 8 ? 8 : 1024 / B;
+    if (bm > cap) bm = cap;
+    hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, dim3(bm, B), dim3(256), 0, s, qkv, ctx, gctx, colM, colS, n, gqkv);
+    return hipGetLastError();
+  }
   int bx = (n + 1) / 2;
   if (bx > 1024) bx = 1024;
   hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(bx, B), dim3(256), 0, s, qkv, ctx, gctx, colM, colS, n, gqkv);
